@@ -1,0 +1,186 @@
+/*
+ * mvdb_hip.h -- C ABI of libmvdb_hip.so, the MI355X (gfx950) query engine for
+ * MiniVectorDB's two-stage retrieval path (search()/searchMany()).
+ *
+ * This is the drop-in boundary: every entry point replaces one function the
+ * reference host (`class WasmBridge`, src/core/wasm-bridge.ts:24) calls on the
+ * WASM module (export list assembly/index.ts:33-67), or one compute loop of
+ * `MiniVectorDB.searchMany` (src/mini-vector-db.ts:560-655).  Reference
+ * file:line citations are relative to the upstream tree.
+ *
+ * Conventions
+ *  - plain C types only; all buffers are caller-owned; no pointer outlives a call.
+ *  - functions returning `int` status: 1 = ok, 0 = failure (mirrors
+ *    load_index, assembly/hnsw.ts:1129); mvdb_last_error() gives the text.
+ *  - "host" entry points take host pointers and are synchronous.
+ *  - "_dev" entry points take DEVICE pointers (HBM) plus a hipStream_t passed as
+ *    void* (NULL = default stream) and are asynchronous on that stream; they are
+ *    what a resident pipeline (and bench.py) uses.
+ *  - one call in flight per handle (the reference serialises every bridge call
+ *    behind a promise-chain mutex, wasm-bridge.ts:39-50).
+ *  - there is NO CPU fallback: without a HIP device every compute call fails.
+ */
+#ifndef MVDB_HIP_H
+#define MVDB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVDB_MAX_EF 4096 /* assembly/hnsw.ts:30 MAX_EF */
+
+typedef struct mvdb_index mvdb_index; /* opaque */
+
+/* WasmBridge InitConfig (wasm-bridge.ts:14-22) + the HIP device ordinal */
+typedef struct mvdb_config {
+	int32_t dim;             /* DIM, multiple of 4 (assembly/config.ts:98)    */
+	int32_t m;               /* M; M_MAX0 = 2*M (config.ts:115)               */
+	int32_t ef_construction; /* EF_CONSTRUCTION: part of the dump compat key  */
+	int32_t ef_search;       /* initial EF_SEARCH (<=0 -> 50, wasm-bridge:80) */
+	int32_t capacity;        /* init_index(capacity)                          */
+	int32_t results_cap;     /* <=0 -> 1000 (wasm-bridge.ts:84)               */
+	uint32_t seed;           /* seed_rng; 0 -> 2463534242 (hnsw.ts:57-59)     */
+	int32_t device;          /* HIP device ordinal; -1 = current device       */
+} mvdb_config;
+
+/* per-query work counters, SURVEY.md section 8(d) byte accounting */
+typedef struct mvdb_query_counters {
+	int32_t n_dist;       /* dist_l2_sq evaluations (hnsw.ts:450,497,969,996) */
+	int32_t n_l0lists;    /* layer-0 nodes expanded (hnsw.ts:468-483)         */
+	int32_t n_upperlists; /* upper-layer list scans (hnsw.ts:975-989)         */
+	int32_t n_found;      /* results returned                                 */
+} mvdb_query_counters;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+/* WasmBridge.init (wasm-bridge.ts:52-103): set_config, set_search_config,
+ * set_results_cap, seed_rng, init_index(capacity).  Invalid dim/m/ef fails
+ * (update_config traps, assembly/config.ts:95-100). */
+int mvdb_create(const mvdb_config *cfg, mvdb_index **out);
+void mvdb_destroy(mvdb_index *h);
+/* text of the last failure on this handle (or of mvdb_create when h == NULL) */
+const char *mvdb_last_error(const mvdb_index *h);
+/* 1 when a gfx950-class HIP device is usable by this process */
+int mvdb_device_available(void);
+
+/* ---- index state (WasmBridge getters/setters) ---------------------------- */
+int mvdb_get_max_ef(void);                        /* get_max_ef, hnsw.ts:90       */
+void mvdb_set_ef_search(mvdb_index *h, int ef);   /* set_search_config, config.ts:127; ef<=0 ignored */
+int mvdb_get_ef_search(const mvdb_index *h);
+void mvdb_set_results_cap(mvdb_index *h, int cap); /* set_results_cap, hnsw.ts:78; cap<=0 ignored, clamp 4096 */
+int mvdb_get_results_cap(const mvdb_index *h);     /* get_results_cap, hnsw.ts:86  */
+int mvdb_has_node(const mvdb_index *h, int id);    /* has_node, hnsw.ts:135        */
+int mvdb_get_max_elements(const mvdb_index *h);    /* get_max_elements, hnsw.ts:103 */
+int mvdb_element_count(const mvdb_index *h);
+int mvdb_was_ef_clamped(const mvdb_index *h);      /* was_ef_clamped, hnsw.ts:94   */
+void mvdb_clear_ef_clamped(mvdb_index *h);         /* clear_ef_clamped, hnsw.ts:98 */
+
+/* ---- dump.bin V3 (hnsw.ts:1033-1249) ------------------------------------- */
+/* load_index + WasmBridge.load (wasm-bridge.ts:377-468): parse/validate the
+ * dump byte-exactly, upload graph + int8 rows to HBM.  On failure the handle
+ * holds a fresh empty index of the configured capacity and 0 is returned. */
+int mvdb_load_dump(mvdb_index *h, const uint8_t *buf, size_t size);
+/* get_index_dump_size / save_index (hnsw.ts:1048, :1075) */
+size_t mvdb_dump_size(const mvdb_index *h);
+size_t mvdb_save_dump(const mvdb_index *h, uint8_t *buf);
+
+/* ---- write path on the host graph (assembly/hnsw.ts:719-953) -------------- */
+/* insert (upsert) / WasmBridge.insertManyPacked (wasm-bridge.ts:268-288).  The
+ * graph is edited on the host and re-uploaded lazily before the next search. */
+int mvdb_insert_many(mvdb_index *h, const int32_t *ids, const int8_t *packed, int n);
+/* update_vector (hnsw.ts:837) */
+int mvdb_update_vector(mvdb_index *h, int id, const int8_t *vec);
+/* Benchmark-data builder: the same insert algorithm run by `threads` workers
+ * (NOT the reference's sequential order).  ids 0..n-1, index must be empty. */
+int mvdb_build_parallel(mvdb_index *h, const int8_t *packed, int n, int threads);
+
+/* ---- float32 store (vectors.f32.bin, src/mini-vector-db.ts:1013-1036) ---- */
+/* Upload `rows` x dim f32 rows (row id at byte id*dim*4) for the rerank stage.
+ * resident=1: copy into HBM (preloadVectors=true analogue).
+ * resident=0: keep in pinned host memory, gathered over the host link. */
+int mvdb_attach_f32(mvdb_index *h, const float *base, int64_t rows, int resident);
+
+/* ---- stage 0: query prep (src/mini-vector-db.ts:963-984) ----------------- */
+/* normalizeF32InPlace + quantizeToI8 for nq x dim f32 queries, bit-exact.
+ * q_norm_out (nq x dim f32) and q_i8_out (nq x dim i8) may each be NULL. */
+int mvdb_prepare_queries(mvdb_index *h, const float *q_in, int nq, float *q_norm_out, int8_t *q_i8_out);
+int mvdb_prepare_queries_dev(mvdb_index *h, const float *d_q_in, int nq, float *d_q_norm_out,
+                             int8_t *d_q_i8_out, void *stream);
+
+/* ---- stage 1: batched HNSW traversal ------------------------------------- */
+/* WasmBridge.searchMany (wasm-bridge.ts:326-355) == nq x search()
+ * (hnsw.ts:960-1027): the effective-ef rule ef = max(EF_SEARCH, k) clamped to
+ * 4096 lives inside.  q: nq x dim packed int8.  out_ids/out_dist: nq x k
+ * row-major (row qi valid for out_count[qi] entries, ascending dist, exactly the
+ * (i32 id, f32 dist) pairs the WASM writes).  ctr: optional nq counters. */
+int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out_ids, float *out_dist,
+                     int32_t *out_count, mvdb_query_counters *ctr);
+int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids,
+                         float *d_out_dist, int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream);
+/* WasmBridge.search (wasm-bridge.ts:301-321): one query, returns the count */
+int mvdb_search(mvdb_index *h, const int8_t *q, int k, int32_t *out_ids, float *out_dist);
+
+/* ---- stage 2: float32 rerank + top-k (src/mini-vector-db.ts:606-651) ------ */
+/* For each query: walk cand[qi][0..cand_count) in ANN order keeping ids whose
+ * bit is set in `allow` (NULL = all; replaces the per-candidate metadata /
+ * deleted / filter checks :610-616), at most ann_k; L2^2 against the f32 row in
+ * f64 exactly as l2SqF32 (:986-993); order by (l2 asc, id asc) (:637); emit the
+ * first topk.  out_ids/out_l2: nq x topk, out_n[nq]. */
+int mvdb_rerank_many(mvdb_index *h, const float *q_f32, int nq, const int32_t *cand,
+                     const int32_t *cand_count, int stride, int ann_k, const uint32_t *allow, int topk,
+                     int32_t *out_ids, double *out_l2, int32_t *out_n);
+int mvdb_rerank_many_dev(mvdb_index *h, const float *d_q_f32, int nq, const int32_t *d_cand,
+                         const int32_t *d_cand_count, int stride, int ann_k, const uint32_t *d_allow,
+                         int topk, int32_t *d_out_ids, double *d_out_l2, int32_t *d_out_n, void *stream);
+
+/* ---- fused searchMany (src/mini-vector-db.ts:560-655) --------------------- */
+/* prep -> traversal (k = ann_k) -> filter -> rerank -> topk, all on device.
+ * ef_search / ann_k are the values derived at :571-576 (mvdb_derive_params).
+ * d_allow: device bitmap over internal ids or NULL.  Outputs nq x topk. */
+int mvdb_query_many_dev(mvdb_index *h, const float *d_q_f32, int nq, int topk, int ef_search, int ann_k,
+                        const uint32_t *d_allow, int32_t *d_out_ids, double *d_out_l2, int32_t *d_out_n,
+                        mvdb_query_counters *d_ctr, void *stream);
+int mvdb_query_many(mvdb_index *h, const float *q_f32, int nq, int topk, int ef_search, int ann_k,
+                    const uint32_t *allow, int32_t *out_ids, double *out_l2, int32_t *out_n,
+                    mvdb_query_counters *ctr);
+/* ef / annK derivation (mini-vector-db.ts:568-576) and the results-cap growth
+ * rule ensureResultsCapAtLeast (:1160-1170), host-only helpers */
+void mvdb_derive_params(int topk_in, int base_ef_search, int rerank_multiplier, int max_ann_k, int *topk,
+                        int *ef_search, int *ann_k);
+void mvdb_ensure_results_cap_at_least(mvdb_index *h, int n);
+/* toScore (mini-vector-db.ts:995-1001): mode 0 "l2", 1 "cosine", else "sim" */
+double mvdb_to_score(double l2, int mode);
+
+/* ---- int8 distance kernels (assembly/math.ts) ----------------------------- */
+/* dist_l2_i8 (:115) / dot_i8 (:133) of query qi against node ids[qi][j]:
+ * out[qi][j] = exact i32 (ids < 0 or absent -> INT32_MIN).  metric 0 = L2, 1 = dot. */
+int mvdb_dist_many(mvdb_index *h, const int8_t *q, int nq, const int32_t *ids, int per_q, int metric,
+                   int32_t *out);
+/* exact brute-force int8 scan over all present nodes; order (dist asc, id asc)
+ * for L2, (dot desc, id asc) for dot; k <= 128.  No reference counterpart
+ * (north_star kernel #2); parity target is the oracle's mvo_scan_many. */
+int mvdb_scan_many(mvdb_index *h, const int8_t *q, int nq, int k, int metric, int32_t *out_ids,
+                   int32_t *out_val, int32_t *out_count);
+int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metric, int32_t *d_out_ids,
+                       int32_t *d_out_val, int32_t *d_out_count, void *stream);
+
+/* ---- top-k merge for id-range shards --------------- */
+/* Merge `parts` per-shard results (each nq x topk, ids already global) into
+ * nq x topk ordered by (l2 asc, id asc).  Inputs laid out [part][nq][topk]. */
+int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2, const int32_t *d_n,
+                        int parts, int nq, int topk, int32_t *d_out_ids, double *d_out_l2,
+                        int32_t *d_out_n, void *stream);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* average device time (ms) of the last launch of each stage, measured with HIP
+ * events on the launching stream when timing is enabled. stage: 0 prep,
+ * 1 traversal, 2 rerank, 3 scan. Returns <0 when no sample exists. */
+void mvdb_enable_timing(mvdb_index *h, int on);
+float mvdb_last_stage_ms(mvdb_index *h, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+// device_index.hpp -- HBM-resident mirror of HostGraph, laid out for wave64 traversal.
+//
+// Layout (all 256-B aligned hipMalloc allocations):
+//   vec   int8 [max_elements][row_stride]   row_stride = round_up(dim,16); pad bytes are 0, so
+//                                           they add nothing to L2 / dot sums
+//   adj0  int32[max_elements][m0]           layer-0 lists, CANONICALISED at upload: only ids that
+//                                           the reference's scan would not skip (in range, present,
+//                                           first occurrence, not the node itself), in list order,
+//                                           -1 padded.  One 128-B line per node at m0 = 32.
+//   upper int2 [n_upper_lists][m]           upper-layer lists of nodes with level >= 1, layer 1
+//                                           first.  Entry = (neighbour id, code) with
+//                                           code = (cum << 2) | level, cum = index of the
+//                                           neighbour's own layer-1 list, so a walk never needs a
+//                                           per-node offset lookup.  (-1,-1) padded.
+// Why canonicalising is exact: search_layer skips ids <0, >=max_elements, absent or already
+// visited (hnsw.ts:488-494) BEFORE computing a distance; a repeated id or the expanded node itself
+// is always visited by then.  Upper lists drop only what the descent skips before its distance
+// (out of range / absent, hnsw.ts:993-994); repeats and self stay, so even the work counters
+// match the reference on foreign dumps.
+#pragma once
+
+#include <cstdint>
+#include <string>
+
+#include "host_graph.hpp"
+
+namespace mvdb {
+
+struct DevIndexView {
+	const int8_t *vec;
+	const int32_t *adj0;
+	const int2 *upper;
+	int32_t dim, row_stride, m, m0, max_elements;
+	int32_t entry, entry_code, max_level;
+};
+
+class DeviceIndex {
+public:
+	DevIndexView view{};
+	const int32_t *norm2 = nullptr;  // |v|^2 per id, -1 = absent (exact scan only)
+	uint64_t built_version = ~0ull;
+	size_t bytes_vec = 0, bytes_adj0 = 0, bytes_upper = 0;
+
+	~DeviceIndex() { release(); }
+	// (re)build from the host graph; returns false and sets err on HIP failure
+	bool upload(const HostGraph &g, std::string &err);
+	void release();
+
+private:
+	void *d_vec_ = nullptr, *d_adj0_ = nullptr, *d_upper_ = nullptr, *d_norm2_ = nullptr;
+};
+
+}  // namespace mvdb

@@ -1,0 +1,881 @@
+// engine.hip -- C ABI of libmvdb_hip.so (include/mvdb_hip.h): host graph + device mirror +
+// kernel launches.  gfx950 only; no CPU fallback for any compute entry point.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device_index.hpp"
+#include "host_graph.hpp"
+#include "mvdb_hip.h"
+#include "rerank.hip.hpp"
+#include "scan.hip.hpp"
+#include "traverse.hip.hpp"
+
+using namespace mvdb;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIP_OK(h, expr)                                                                         \
+	do {                                                                                        \
+		hipError_t e_ = (expr);                                                                 \
+		if (e_ != hipSuccess) {                                                                 \
+			(h)->set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+			return 0;                                                                           \
+		}                                                                                       \
+	} while (0)
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	~DevBuf() { (void)hipFree(p); }
+	// grow-only scratch; returns nullptr on failure
+	void *need(size_t bytes)
+	{
+		if (bytes <= cap && p) return p;
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+		size_t want = std::max<size_t>(bytes, 256);
+		if (hipMalloc(&p, want) != hipSuccess) {
+			p = nullptr;
+			return nullptr;
+		}
+		cap = want;
+		return p;
+	}
+};
+
+}  // namespace
+
+// --------------------------------------------------------------------------- DeviceIndex
+void DeviceIndex::release()
+{
+	(void)hipFree(d_vec_);
+	(void)hipFree(d_adj0_);
+	(void)hipFree(d_upper_);
+	(void)hipFree(d_norm2_);
+	d_vec_ = d_adj0_ = d_upper_ = d_norm2_ = nullptr;
+	norm2 = nullptr;
+	view = DevIndexView{};
+	built_version = ~0ull;
+}
+
+bool DeviceIndex::upload(const HostGraph &g, std::string &err)
+{
+	release();
+	const int N = g.max_elements, dim = g.cfg.dim, m = g.cfg.m, m0 = g.cfg.m0();
+	const int stride = (dim + 15) & ~15;
+	view.dim = dim;
+	view.row_stride = stride;
+	view.m = m;
+	view.m0 = m0;
+	view.max_elements = N;
+	view.entry = g.entry_point;
+	view.max_level = g.max_level;
+	view.entry_code = 0;
+	built_version = g.version;
+	if (N <= 0) return true;
+
+	// cum[id] = index of the node's layer-1 list among all upper lists
+	std::vector<int32_t> code((size_t)N, 0);
+	int64_t n_lists = 0;
+	for (int i = 0; i < N; i++) {
+		const int lvl = g.level[i];
+		if (lvl < 0) continue;
+		if (n_lists > (int64_t)0x1fffffff) {
+			err = "too many upper-layer lists for the 29-bit list index";
+			return false;
+		}
+		code[i] = (int32_t)((n_lists << 2) | lvl);
+		n_lists += lvl;
+	}
+	if (g.present(g.entry_point)) view.entry_code = code[g.entry_point];
+
+	auto check = [&](hipError_t e, const char *what) {
+		if (e == hipSuccess) return true;
+		err = std::string(what) + ": " + hipGetErrorString(e);
+		return false;
+	};
+
+	// int8 rows, padded to the 16-byte stride
+	bytes_vec = (size_t)N * stride;
+	if (!check(hipMalloc(&d_vec_, std::max<size_t>(bytes_vec, 256)), "hipMalloc(vec)")) return false;
+	if (stride == dim) {
+		if (!check(hipMemcpy(d_vec_, g.vec.data(), bytes_vec, hipMemcpyHostToDevice), "copy vec")) return false;
+	} else {
+		if (!check(hipMemset(d_vec_, 0, bytes_vec), "memset vec")) return false;
+		if (!check(hipMemcpy2D(d_vec_, stride, g.vec.data(), dim, dim, N, hipMemcpyHostToDevice), "copy vec 2D"))
+			return false;
+	}
+
+	// |v|^2 per node for the exact scan, -1 marks an absent id
+	{
+		std::vector<int32_t> n2((size_t)N, -1);
+		for (int i = 0; i < N; i++)
+			if (g.level[i] >= 0) n2[i] = dot_i8(g.row(i), g.row(i), dim);
+		if (!check(hipMalloc(&d_norm2_, std::max<size_t>((size_t)N * 4, 256)), "hipMalloc(norm2)")) return false;
+		if (!check(hipMemcpy(d_norm2_, n2.data(), (size_t)N * 4, hipMemcpyHostToDevice), "copy norm2")) return false;
+		norm2 = static_cast<const int32_t *>(d_norm2_);
+	}
+
+	// layer 0, canonicalised (see device_index.hpp)
+	{
+		std::vector<int32_t> adj((size_t)N * m0, -1);
+		for (int i = 0; i < N; i++) {
+			if (g.level[i] < 0) continue;
+			const int32_t *src = g.adj0.data() + (size_t)i * m0;
+			int32_t *dst = adj.data() + (size_t)i * m0;
+			const int cnt = std::clamp(g.cnt0[i], 0, m0);
+			int w = 0;
+			for (int j = 0; j < cnt; j++) {
+				const int nb = src[j];
+				if (!g.present(nb) || nb == i) continue;
+				if (std::find(dst, dst + w, nb) != dst + w) continue;
+				dst[w++] = nb;
+			}
+		}
+		bytes_adj0 = adj.size() * 4;
+		if (!check(hipMalloc(&d_adj0_, std::max<size_t>(bytes_adj0, 256)), "hipMalloc(adj0)")) return false;
+		if (!check(hipMemcpy(d_adj0_, adj.data(), bytes_adj0, hipMemcpyHostToDevice), "copy adj0")) return false;
+	}
+	// upper layers as (id, code) pairs
+	{
+		std::vector<int2> up((size_t)n_lists * m, make_int2(-1, -1));
+		for (int i = 0; i < N; i++) {
+			const int lvl = g.level[i];
+			if (lvl < 1) continue;
+			const int64_t cum = code[i] >> 2;
+			for (int l = 1; l <= lvl; l++) {
+				const int32_t *rec = g.upper.data() + g.upper_off[i] + (size_t)(l - 1) * (1 + m);
+				const int cnt = std::clamp(rec[0], 0, m);
+				int2 *dst = up.data() + (size_t)(cum + l - 1) * m;
+				int w = 0;
+				for (int j = 0; j < cnt; j++) {
+					const int nb = rec[1 + j];
+					if (!g.present(nb)) continue;
+					dst[w++] = make_int2(nb, code[nb]);
+				}
+			}
+		}
+		bytes_upper = up.size() * sizeof(int2);
+		if (!check(hipMalloc(&d_upper_, std::max<size_t>(bytes_upper, 256)), "hipMalloc(upper)")) return false;
+		if (bytes_upper &&
+		    !check(hipMemcpy(d_upper_, up.data(), bytes_upper, hipMemcpyHostToDevice), "copy upper"))
+			return false;
+	}
+	view.vec = static_cast<const int8_t *>(d_vec_);
+	view.adj0 = static_cast<const int32_t *>(d_adj0_);
+	view.upper = static_cast<const int2 *>(d_upper_);
+	return true;
+}
+
+// --------------------------------------------------------------------------- handle
+struct mvdb_index {
+	mvdb_config cfg{};
+	HostGraph g;
+	DeviceIndex dev;
+	int ef_search = 50;  // EF_SEARCH, assembly/config.ts:54
+	std::string err;
+	int device = 0;
+
+	// f32 store
+	float *f32_dev = nullptr;    // resident copy
+	float *f32_pinned = nullptr;  // host-pinned copy (device-mapped)
+	const float *f32_ptr = nullptr;  // pointer the rerank kernel dereferences
+	int64_t f32_rows = 0;
+
+	// scratch
+	DevBuf visited, st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
+		st_misc, scan_part;
+
+	bool timing = false;
+	hipEvent_t ev0[4] = {nullptr, nullptr, nullptr, nullptr}, ev1[4] = {nullptr, nullptr, nullptr, nullptr};
+	bool ev_pending[4] = {false, false, false, false};
+	float stage_ms[4] = {-1.f, -1.f, -1.f, -1.f};
+
+	void set_error(const std::string &s) { err = s; }
+	~mvdb_index()
+	{
+		(void)hipFree(f32_dev);
+		if (f32_pinned) (void)hipHostFree(f32_pinned);
+		for (int i = 0; i < 4; i++) {
+			if (ev0[i]) (void)hipEventDestroy(ev0[i]);
+			if (ev1[i]) (void)hipEventDestroy(ev1[i]);
+		}
+	}
+};
+
+namespace {
+
+// WasmBridge.init / reinitFresh (wasm-bridge.ts:52-103, :383-418)
+void bridge_reinit(mvdb_index *h)
+{
+	h->ef_search = 50;
+	if (h->cfg.ef_search > 0) h->ef_search = h->cfg.ef_search;
+	h->g.results_cap = 1000;
+	{
+		int cap = h->cfg.results_cap;  // `config.resultsCap ?? 1000` then clampResultsCap :105-110
+		if (cap <= 0) cap = 1;
+		h->g.results_cap = std::min(cap, kMaxEf);
+	}
+	h->g.seed(h->cfg.seed);
+	GraphConfig gc;
+	gc.dim = h->cfg.dim;
+	gc.m = h->cfg.m;
+	gc.ef_construction = h->cfg.ef_construction;
+	h->g.init(gc, h->cfg.capacity);
+}
+
+int ensure_device(mvdb_index *h)
+{
+	HIP_OK(h, hipSetDevice(h->device));
+	return 1;
+}
+
+int ensure_uploaded(mvdb_index *h)
+{
+	if (!ensure_device(h)) return 0;
+	if (h->dev.built_version == h->g.version) return 1;
+	std::string e;
+	if (!h->dev.upload(h->g, e)) {
+		h->set_error("device upload failed: " + e);
+		return 0;
+	}
+	return 1;
+}
+
+// device time of a stage: HIP events recorded on the launching stream; read lazily
+struct StageTimer {
+	mvdb_index *h;
+	int stage;
+	hipStream_t s;
+	StageTimer(mvdb_index *h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_)
+	{
+		if (!h->timing) return;
+		if (!h->ev0[stage]) {
+			(void)hipEventCreate(&h->ev0[stage]);
+			(void)hipEventCreate(&h->ev1[stage]);
+		}
+		(void)hipEventRecord(h->ev0[stage], s);
+	}
+	~StageTimer()
+	{
+		if (!h->timing) return;
+		(void)hipEventRecord(h->ev1[stage], s);
+		h->ev_pending[stage] = true;
+	}
+};
+
+template <int J, bool FULL>
+int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
+{
+	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&traverse_kernel<J, FULL>),
+	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((traverse_kernel<J, FULL>), dim3(a.nq), dim3(64), lds, s, a);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
+{
+	const size_t lds = traverse_lds_bytes(a.ef, a.cand_cap);
+	const int stride = a.ix.row_stride;
+	const int J = (stride + 127) / 128;
+	const bool full = stride == J * 128;
+#define MVDB_T(JJ)                                                      \
+	if (J <= JJ) {                                                      \
+		if (full && J == JJ) return launch_traverse_t<JJ, true>(h, a, lds, s); \
+		return launch_traverse_t<JJ, false>(h, a, lds, s);              \
+	}
+	MVDB_T(1)
+	MVDB_T(2)
+	MVDB_T(3)
+	MVDB_T(4)
+	MVDB_T(6)
+	MVDB_T(8)
+	MVDB_T(12)
+	MVDB_T(16)
+#undef MVDB_T
+	h->set_error("dim > 2048 is not supported by the traversal kernel");
+	return 0;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int mvdb_device_available(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n > 0;
+}
+
+int mvdb_create(const mvdb_config *cfg, mvdb_index **out)
+{
+	if (!cfg || !out) {
+		g_create_error = "null argument";
+		return 0;
+	}
+	*out = nullptr;
+	// update_config validations, assembly/config.ts:95-100 (the WASM traps)
+	if (cfg->dim <= 0 || (cfg->dim & 3) != 0 || cfg->m <= 0 || cfg->ef_construction <= 0) {
+		g_create_error = "invalid config: dim must be a positive multiple of 4, m and ef_construction positive";
+		return 0;
+	}
+	std::unique_ptr<mvdb_index> h(new mvdb_index());
+	h->cfg = *cfg;
+	if (cfg->device >= 0) h->device = cfg->device;
+	else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+	bridge_reinit(h.get());
+	*out = h.release();
+	return 1;
+}
+
+void mvdb_destroy(mvdb_index *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->device);
+	delete h;
+}
+
+const char *mvdb_last_error(const mvdb_index *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mvdb_get_max_ef(void) { return kMaxEf; }
+void mvdb_set_ef_search(mvdb_index *h, int ef)
+{
+	if (ef <= 0) return;  // config.ts:128
+	h->ef_search = ef;
+}
+int mvdb_get_ef_search(const mvdb_index *h) { return h->ef_search; }
+void mvdb_set_results_cap(mvdb_index *h, int cap)
+{
+	if (cap <= 0) return;  // hnsw.ts:81
+	h->g.results_cap = std::min(cap, kMaxEf);
+}
+int mvdb_get_results_cap(const mvdb_index *h) { return h->g.results_cap; }
+int mvdb_has_node(const mvdb_index *h, int id) { return h->g.present(id) ? 1 : 0; }
+int mvdb_get_max_elements(const mvdb_index *h) { return h->g.max_elements; }
+int mvdb_element_count(const mvdb_index *h) { return h->g.element_count; }
+int mvdb_was_ef_clamped(const mvdb_index *h) { return h->g.ef_clamped ? 1 : 0; }
+void mvdb_clear_ef_clamped(mvdb_index *h) { h->g.ef_clamped = false; }
+
+int mvdb_load_dump(mvdb_index *h, const uint8_t *buf, size_t size)
+{
+	// WasmBridge.load :421-452: reset + re-apply config, then load_index
+	bridge_reinit(h);
+	if (!buf || !h->g.load(buf, size)) {
+		bridge_reinit(h);  // reinitFresh :463-466
+		h->set_error("WASM load_index failed (format mismatch / config mismatch / corrupt dump).");
+		return 0;
+	}
+	return 1;
+}
+size_t mvdb_dump_size(const mvdb_index *h) { return h->g.dump_size(); }
+size_t mvdb_save_dump(const mvdb_index *h, uint8_t *buf) { return h->g.save(buf); }
+
+int mvdb_insert_many(mvdb_index *h, const int32_t *ids, const int8_t *packed, int n)
+{
+	for (int i = 0; i < n; i++) h->g.insert(ids[i], packed + (size_t)i * h->cfg.dim);
+	return 1;
+}
+int mvdb_update_vector(mvdb_index *h, int id, const int8_t *vec)
+{
+	h->g.update_vector(id, vec);
+	return 1;
+}
+int mvdb_build_parallel(mvdb_index *h, const int8_t *packed, int n, int threads)
+{
+	if (h->g.element_count != 0) {
+		h->set_error("mvdb_build_parallel needs an empty index");
+		return 0;
+	}
+	h->g.build_parallel(packed, n, threads);
+	return 1;
+}
+
+int mvdb_attach_f32(mvdb_index *h, const float *base, int64_t rows, int resident)
+{
+	if (!ensure_device(h)) return 0;
+	(void)hipFree(h->f32_dev);
+	h->f32_dev = nullptr;
+	if (h->f32_pinned) (void)hipHostFree(h->f32_pinned);
+	h->f32_pinned = nullptr;
+	h->f32_ptr = nullptr;
+	h->f32_rows = 0;
+	if (!base || rows <= 0) return 1;
+	const size_t bytes = (size_t)rows * h->cfg.dim * sizeof(float);
+	if (resident) {
+		HIP_OK(h, hipMalloc(reinterpret_cast<void **>(&h->f32_dev), bytes));
+		HIP_OK(h, hipMemcpy(h->f32_dev, base, bytes, hipMemcpyHostToDevice));
+		h->f32_ptr = h->f32_dev;
+	} else {
+		HIP_OK(h, hipHostMalloc(reinterpret_cast<void **>(&h->f32_pinned), bytes, hipHostMallocMapped));
+		std::memcpy(h->f32_pinned, base, bytes);
+		void *dp = nullptr;
+		HIP_OK(h, hipHostGetDevicePointer(&dp, h->f32_pinned, 0));
+		h->f32_ptr = static_cast<const float *>(dp);
+	}
+	h->f32_rows = rows;
+	return 1;
+}
+
+// ---- stage 0
+int mvdb_prepare_queries_dev(mvdb_index *h, const float *d_q_in, int nq, float *d_q_norm_out, int8_t *d_q_i8_out,
+                             void *stream)
+{
+	if (!ensure_device(h)) return 0;
+	if (nq <= 0) return 1;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	StageTimer t(h, 0, s);
+	hipLaunchKernelGGL(prep_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_q_in, nq, h->cfg.dim, d_q_norm_out,
+	                   d_q_i8_out);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+int mvdb_prepare_queries(mvdb_index *h, const float *q_in, int nq, float *q_norm_out, int8_t *q_i8_out)
+{
+	if (!ensure_device(h)) return 0;
+	if (nq <= 0) return 1;
+	const size_t n = (size_t)nq * h->cfg.dim;
+	float *d_in = static_cast<float *>(h->st_misc.need(n * 4));
+	float *d_qf = static_cast<float *>(h->st_qf.need(n * 4));
+	int8_t *d_q8 = static_cast<int8_t *>(h->st_q8.need(n));
+	if (!d_in || !d_qf || !d_q8) {
+		h->set_error("out of device memory (query staging)");
+		return 0;
+	}
+	HIP_OK(h, hipMemcpy(d_in, q_in, n * 4, hipMemcpyHostToDevice));
+	if (!mvdb_prepare_queries_dev(h, d_in, nq, d_qf, d_q8, nullptr)) return 0;
+	if (q_norm_out) HIP_OK(h, hipMemcpy(q_norm_out, d_qf, n * 4, hipMemcpyDeviceToHost));
+	if (q_i8_out) HIP_OK(h, hipMemcpy(q_i8_out, d_q8, n, hipMemcpyDeviceToHost));
+	HIP_OK(h, hipDeviceSynchronize());
+	return 1;
+}
+
+// ---- stage 1
+int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids, float *d_out_dist,
+                         int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0) return 1;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const HostGraph &g = h->g;
+	// search() early-outs, hnsw.ts:961-967 -> count 0 for every query
+	if (g.entry_point == -1 || g.max_elements <= 0 || k <= 0 || !g.present(g.entry_point)) {
+		HIP_OK(h, hipMemsetAsync(d_out_count, 0, (size_t)nq * 4, s));
+		if (d_ctr) HIP_OK(h, hipMemsetAsync(d_ctr, 0, (size_t)nq * sizeof(mvdb_query_counters), s));
+		return 1;
+	}
+	int ef = h->ef_search;  // hnsw.ts:1006-1011
+	if (ef < k) ef = k;
+	if (ef > kMaxEf) {
+		ef = kMaxEf;
+		h->g.ef_clamped = true;
+	}
+	int cand_cap = ef * 2 + 32;  // hnsw.ts:443-445
+	if (cand_cap > kMaxEf) cand_cap = kMaxEf;
+	if (cand_cap < ef) cand_cap = ef;
+
+	TraverseArgs a;
+	a.ix = h->dev.view;
+	a.k = k;
+	a.ef = ef;
+	a.cand_cap = cand_cap;
+	a.results_cap = g.results_cap;
+	a.vis_words = ((size_t)g.max_elements + 31) / 32;
+	// visited bitmaps: bounded scratch, queries are processed in slabs
+	const size_t slab_bytes_max = (size_t)2 << 30;
+	int slab = (int)std::min<size_t>((size_t)nq, std::max<size_t>(1, slab_bytes_max / (a.vis_words * 4)));
+	uint32_t *vis = static_cast<uint32_t *>(h->visited.need((size_t)slab * a.vis_words * 4));
+	if (!vis) {
+		h->set_error("out of device memory (visited bitmaps)");
+		return 0;
+	}
+	StageTimer t(h, 1, s);
+	for (int q0 = 0; q0 < nq; q0 += slab) {
+		const int n = std::min(slab, nq - q0);
+		HIP_OK(h, hipMemsetAsync(vis, 0, (size_t)n * a.vis_words * 4, s));
+		a.q = d_q + (size_t)q0 * g.cfg.dim;
+		a.nq = n;
+		a.visited = vis;
+		a.out_ids = d_out_ids + (size_t)q0 * k;
+		a.out_dist = d_out_dist + (size_t)q0 * k;
+		a.out_count = d_out_count + q0;
+		a.ctr = d_ctr ? d_ctr + q0 : nullptr;
+		if (!launch_traverse(h, a, s)) return 0;
+	}
+	return 1;
+}
+
+int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out_ids, float *out_dist,
+                     int32_t *out_count, mvdb_query_counters *ctr)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0) return 1;
+	const int kk = std::max(k, 1);
+	const size_t nqd = (size_t)nq * h->cfg.dim, nk = (size_t)nq * kk;
+	int8_t *d_q = static_cast<int8_t *>(h->st_q8.need(nqd));
+	int32_t *d_ids = static_cast<int32_t *>(h->st_ids.need(nk * 4));
+	float *d_dist = static_cast<float *>(h->st_dist.need(nk * 4));
+	int32_t *d_cnt = static_cast<int32_t *>(h->st_cnt.need((size_t)nq * 4));
+	mvdb_query_counters *d_ctr =
+		static_cast<mvdb_query_counters *>(h->st_ctr.need((size_t)nq * sizeof(mvdb_query_counters)));
+	if (!d_q || !d_ids || !d_dist || !d_cnt || !d_ctr) {
+		h->set_error("out of device memory (search staging)");
+		return 0;
+	}
+	HIP_OK(h, hipMemcpy(d_q, q, nqd, hipMemcpyHostToDevice));
+	if (!mvdb_search_many_dev(h, d_q, nq, k, d_ids, d_dist, d_cnt, d_ctr, nullptr)) return 0;
+	HIP_OK(h, hipDeviceSynchronize());
+	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+	if (k > 0) {
+		HIP_OK(h, hipMemcpy(out_ids, d_ids, nk * 4, hipMemcpyDeviceToHost));
+		HIP_OK(h, hipMemcpy(out_dist, d_dist, nk * 4, hipMemcpyDeviceToHost));
+	}
+	if (ctr) HIP_OK(h, hipMemcpy(ctr, d_ctr, (size_t)nq * sizeof(mvdb_query_counters), hipMemcpyDeviceToHost));
+	return 1;
+}
+
+int mvdb_search(mvdb_index *h, const int8_t *q, int k, int32_t *out_ids, float *out_dist)
+{
+	int32_t cnt = 0;
+	if (!mvdb_search_many(h, q, 1, k, out_ids, out_dist, &cnt, nullptr)) return -1;
+	return cnt;
+}
+
+// ---- stage 2
+int mvdb_rerank_many_dev(mvdb_index *h, const float *d_q_f32, int nq, const int32_t *d_cand,
+                         const int32_t *d_cand_count, int stride, int ann_k, const uint32_t *d_allow, int topk,
+                         int32_t *d_out_ids, double *d_out_l2, int32_t *d_out_n, void *stream)
+{
+	if (!ensure_device(h)) return 0;
+	if (nq <= 0) return 1;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (topk <= 0 || stride <= 0 || ann_k <= 0 || !h->f32_ptr) {
+		if (!h->f32_ptr && topk > 0) {
+			h->set_error("no float32 store attached (mvdb_attach_f32)");
+			return 0;
+		}
+		HIP_OK(h, hipMemsetAsync(d_out_n, 0, (size_t)nq * 4, s));
+		return 1;
+	}
+	RerankArgs a;
+	a.q = d_q_f32;
+	a.base = h->f32_ptr;
+	a.rows = h->f32_rows;
+	a.dim = h->cfg.dim;
+	a.nq = nq;
+	a.cand = d_cand;
+	a.cand_count = d_cand_count;
+	a.stride = stride;
+	a.ann_k = ann_k;
+	a.topk = topk;
+	a.allow = d_allow;
+	a.out_ids = d_out_ids;
+	a.out_l2 = d_out_l2;
+	a.out_n = d_out_n;
+	const int cap = std::min(stride, ann_k);
+	const size_t lds = rerank_lds_bytes(a.dim, cap);
+	if (lds > 160 * 1024) {
+		h->set_error("rerank: candidate list too long for LDS");
+		return 0;
+	}
+	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&rerank_kernel),
+	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	StageTimer t(h, 2, s);
+	hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(kRerankThreads), lds, s, a, cap);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+int mvdb_rerank_many(mvdb_index *h, const float *q_f32, int nq, const int32_t *cand, const int32_t *cand_count,
+                     int stride, int ann_k, const uint32_t *allow, int topk, int32_t *out_ids, double *out_l2,
+                     int32_t *out_n)
+{
+	if (!ensure_device(h)) return 0;
+	if (nq <= 0) return 1;
+	const size_t nqd = (size_t)nq * h->cfg.dim;
+	const int tk = std::max(topk, 1), st = std::max(stride, 1);
+	float *d_q = static_cast<float *>(h->st_qf.need(nqd * 4));
+	int32_t *d_cand = static_cast<int32_t *>(h->st_ids.need((size_t)nq * st * 4));
+	int32_t *d_cnt = static_cast<int32_t *>(h->st_cnt.need((size_t)nq * 4));
+	int32_t *d_oi = static_cast<int32_t *>(h->st_out_ids.need((size_t)nq * tk * 4));
+	double *d_ol = static_cast<double *>(h->st_out_l2.need((size_t)nq * tk * 8));
+	int32_t *d_on = static_cast<int32_t *>(h->st_out_n.need((size_t)nq * 4));
+	uint32_t *d_allow = nullptr;
+	if (allow) {
+		const size_t words = ((size_t)std::max<int64_t>(h->g.max_elements, 1) + 31) / 32;
+		d_allow = static_cast<uint32_t *>(h->st_allow.need(words * 4));
+		if (!d_allow) {
+			h->set_error("out of device memory (allow bitmap)");
+			return 0;
+		}
+		HIP_OK(h, hipMemcpy(d_allow, allow, words * 4, hipMemcpyHostToDevice));
+	}
+	if (!d_q || !d_cand || !d_cnt || !d_oi || !d_ol || !d_on) {
+		h->set_error("out of device memory (rerank staging)");
+		return 0;
+	}
+	HIP_OK(h, hipMemcpy(d_q, q_f32, nqd * 4, hipMemcpyHostToDevice));
+	if (stride > 0) HIP_OK(h, hipMemcpy(d_cand, cand, (size_t)nq * stride * 4, hipMemcpyHostToDevice));
+	HIP_OK(h, hipMemcpy(d_cnt, cand_count, (size_t)nq * 4, hipMemcpyHostToDevice));
+	if (!mvdb_rerank_many_dev(h, d_q, nq, d_cand, d_cnt, stride, ann_k, d_allow, topk, d_oi, d_ol, d_on, nullptr))
+		return 0;
+	HIP_OK(h, hipDeviceSynchronize());
+	HIP_OK(h, hipMemcpy(out_n, d_on, (size_t)nq * 4, hipMemcpyDeviceToHost));
+	if (topk > 0) {
+		HIP_OK(h, hipMemcpy(out_ids, d_oi, (size_t)nq * topk * 4, hipMemcpyDeviceToHost));
+		HIP_OK(h, hipMemcpy(out_l2, d_ol, (size_t)nq * topk * 8, hipMemcpyDeviceToHost));
+	}
+	return 1;
+}
+
+// ---- fused searchMany
+void mvdb_derive_params(int topk_in, int base_ef_search, int rerank_multiplier, int max_ann_k, int *topk,
+                        int *ef_search, int *ann_k)
+{
+	const int tk = std::max(1, topk_in);                     // :568
+	const int ef = std::max(base_ef_search, tk * 2);         // :571
+	int annK = std::max(tk, tk * rerank_multiplier);         // :574
+	annK = std::min(annK, max_ann_k);                        // :575
+	annK = std::min(annK, kMaxEf);                           // :576 (wasmMaxEf = 4096)
+	if (topk) *topk = tk;
+	if (ef_search) *ef_search = ef;
+	if (ann_k) *ann_k = annK;
+}
+
+void mvdb_ensure_results_cap_at_least(mvdb_index *h, int n)
+{
+	if (n <= 0) return;  // :1161
+	n = std::min(n, kMaxEf);
+	const int cur = mvdb_get_results_cap(h);
+	if (cur >= n) return;
+	int next = cur > 0 ? cur : 1000;
+	while (next < n) next *= 2;
+	// WasmBridge.setResultsCap -> clampResultsCap (wasm-bridge.ts:105-110, :179-185)
+	mvdb_set_results_cap(h, std::min(std::max(next, 1), kMaxEf));
+}
+
+double mvdb_to_score(double l2, int mode)
+{
+	if (mode == 0) return l2;
+	const double cosine = 1 - l2 / 2;
+	if (mode == 1) return std::fmax(-1.0, std::fmin(1.0, cosine));
+	const double sim = 1 - l2 / 4;
+	return std::fmax(0.0, std::fmin(1.0, sim));
+}
+
+int mvdb_query_many_dev(mvdb_index *h, const float *d_q_f32, int nq, int topk, int ef_search, int ann_k,
+                        const uint32_t *d_allow, int32_t *d_out_ids, double *d_out_l2, int32_t *d_out_n,
+                        mvdb_query_counters *d_ctr, void *stream)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0) return 1;
+	mvdb_set_ef_search(h, ef_search);                 // :572
+	mvdb_ensure_results_cap_at_least(h, ann_k);       // :577
+	const size_t nqd = (size_t)nq * h->cfg.dim;
+	const int ak = std::max(ann_k, 1);
+	float *d_qf = static_cast<float *>(h->st_qf.need(nqd * 4));
+	int8_t *d_q8 = static_cast<int8_t *>(h->st_q8.need(nqd));
+	int32_t *d_ids = static_cast<int32_t *>(h->st_ids.need((size_t)nq * ak * 4));
+	float *d_dist = static_cast<float *>(h->st_dist.need((size_t)nq * ak * 4));
+	int32_t *d_cnt = static_cast<int32_t *>(h->st_cnt.need((size_t)nq * 4));
+	if (!d_qf || !d_q8 || !d_ids || !d_dist || !d_cnt) {
+		h->set_error("out of device memory (query pipeline scratch)");
+		return 0;
+	}
+	if (!mvdb_prepare_queries_dev(h, d_q_f32, nq, d_qf, d_q8, stream)) return 0;               // :582-591
+	if (!mvdb_search_many_dev(h, d_q8, nq, ann_k, d_ids, d_dist, d_cnt, d_ctr, stream)) return 0;  // :593
+	return mvdb_rerank_many_dev(h, d_qf, nq, d_ids, d_cnt, ak, ann_k, d_allow, topk, d_out_ids, d_out_l2, d_out_n,
+	                            stream);                                                       // :606-651
+}
+
+int mvdb_query_many(mvdb_index *h, const float *q_f32, int nq, int topk, int ef_search, int ann_k,
+                    const uint32_t *allow, int32_t *out_ids, double *out_l2, int32_t *out_n,
+                    mvdb_query_counters *ctr)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0) return 1;
+	const size_t nqd = (size_t)nq * h->cfg.dim;
+	const int tk = std::max(topk, 1);
+	float *d_in = static_cast<float *>(h->st_misc.need(nqd * 4));
+	int32_t *d_oi = static_cast<int32_t *>(h->st_out_ids.need((size_t)nq * tk * 4));
+	double *d_ol = static_cast<double *>(h->st_out_l2.need((size_t)nq * tk * 8));
+	int32_t *d_on = static_cast<int32_t *>(h->st_out_n.need((size_t)nq * 4));
+	mvdb_query_counters *d_ctr =
+		static_cast<mvdb_query_counters *>(h->st_ctr.need((size_t)nq * sizeof(mvdb_query_counters)));
+	uint32_t *d_allow = nullptr;
+	if (allow) {
+		const size_t words = ((size_t)std::max<int64_t>(h->g.max_elements, 1) + 31) / 32;
+		d_allow = static_cast<uint32_t *>(h->st_allow.need(words * 4));
+		if (!d_allow) {
+			h->set_error("out of device memory (allow bitmap)");
+			return 0;
+		}
+		HIP_OK(h, hipMemcpy(d_allow, allow, words * 4, hipMemcpyHostToDevice));
+	}
+	if (!d_in || !d_oi || !d_ol || !d_on || !d_ctr) {
+		h->set_error("out of device memory (query staging)");
+		return 0;
+	}
+	HIP_OK(h, hipMemcpy(d_in, q_f32, nqd * 4, hipMemcpyHostToDevice));
+	if (!mvdb_query_many_dev(h, d_in, nq, topk, ef_search, ann_k, d_allow, d_oi, d_ol, d_on, d_ctr, nullptr)) return 0;
+	HIP_OK(h, hipDeviceSynchronize());
+	HIP_OK(h, hipMemcpy(out_n, d_on, (size_t)nq * 4, hipMemcpyDeviceToHost));
+	if (topk > 0) {
+		HIP_OK(h, hipMemcpy(out_ids, d_oi, (size_t)nq * topk * 4, hipMemcpyDeviceToHost));
+		HIP_OK(h, hipMemcpy(out_l2, d_ol, (size_t)nq * topk * 8, hipMemcpyDeviceToHost));
+	}
+	if (ctr) HIP_OK(h, hipMemcpy(ctr, d_ctr, (size_t)nq * sizeof(mvdb_query_counters), hipMemcpyDeviceToHost));
+	return 1;
+}
+
+// ---- int8 distances / scan
+int mvdb_dist_many(mvdb_index *h, const int8_t *q, int nq, const int32_t *ids, int per_q, int metric, int32_t *out)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0 || per_q <= 0) return 1;
+	const size_t nqd = (size_t)nq * h->cfg.dim, n = (size_t)nq * per_q;
+	int8_t *d_q = static_cast<int8_t *>(h->st_q8.need(nqd));
+	int32_t *d_ids = static_cast<int32_t *>(h->st_ids.need(n * 4));
+	int32_t *d_out = static_cast<int32_t *>(h->st_dist.need(n * 4));
+	if (!d_q || !d_ids || !d_out) {
+		h->set_error("out of device memory (dist staging)");
+		return 0;
+	}
+	HIP_OK(h, hipMemcpy(d_q, q, nqd, hipMemcpyHostToDevice));
+	HIP_OK(h, hipMemcpy(d_ids, ids, n * 4, hipMemcpyHostToDevice));
+	// presence is host state: absent ids are masked to -1 here so the kernel returns INT32_MIN
+	{
+		std::vector<int32_t> masked(ids, ids + n);
+		for (auto &v : masked)
+			if (!h->g.present(v)) v = -1;
+		HIP_OK(h, hipMemcpy(d_ids, masked.data(), n * 4, hipMemcpyHostToDevice));
+	}
+	const long long pairs = (long long)n;
+	hipLaunchKernelGGL(dist_pairs_kernel, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, nullptr, h->dev.view, d_q,
+	                   d_ids, per_q, pairs, metric, d_out);
+	HIP_OK(h, hipGetLastError());
+	HIP_OK(h, hipDeviceSynchronize());
+	HIP_OK(h, hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+	return 1;
+}
+
+int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metric, int32_t *d_out_ids,
+                       int32_t *d_out_val, int32_t *d_out_count, void *stream)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0) return 1;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (k <= 0 || h->g.max_elements <= 0) {
+		HIP_OK(h, hipMemsetAsync(d_out_count, 0, (size_t)nq * 4, s));
+		return 1;
+	}
+	if (k > kScanMaxK) {
+		h->set_error("mvdb_scan_many: k > 32 is not supported by the fused scan kernel");
+		return 0;
+	}
+	if (h->dev.view.row_stride > 512) {
+		h->set_error("mvdb_scan_many: dim > 512 is not supported by the MFMA scan kernel");
+		return 0;
+	}
+	const int N = h->g.max_elements;
+	ScanArgs a;
+	a.ix = h->dev.view;
+	a.norm2 = h->dev.norm2;
+	a.q = d_q;
+	a.nq = nq;
+	a.k = k;
+	a.metric = metric;
+	a.qtiles = (nq + kScanQB - 1) / kScanQB;
+	a.s2 = scan_s2_for(nq);
+	a.nsplit = 8 * a.s2;
+	a.nodes_per_split = (((N + a.nsplit - 1) / a.nsplit) + kScanTN - 1) / kScanTN * kScanTN;
+	const size_t part_elems = (size_t)nq * a.nsplit * k;
+	unsigned char *part = static_cast<unsigned char *>(h->scan_part.need(part_elems * 8 + (size_t)nq * a.nsplit * 4));
+	if (!part) {
+		h->set_error("out of device memory (scan scratch)");
+		return 0;
+	}
+	a.part_key = reinterpret_cast<unsigned long long *>(part);
+	a.part_n = reinterpret_cast<int32_t *>(part + part_elems * 8);
+	a.out_ids = d_out_ids;
+	a.out_val = d_out_val;
+	a.out_count = d_out_count;
+	StageTimer t(h, 3, s);
+	if (!launch_scan(a, s)) {
+		h->set_error("scan launch failed");
+		return 0;
+	}
+	return 1;
+}
+
+int mvdb_scan_many(mvdb_index *h, const int8_t *q, int nq, int k, int metric, int32_t *out_ids, int32_t *out_val,
+                   int32_t *out_count)
+{
+	if (!ensure_uploaded(h)) return 0;
+	if (nq <= 0) return 1;
+	const size_t nqd = (size_t)nq * h->cfg.dim;
+	const int kk = std::max(k, 1);
+	int8_t *d_q = static_cast<int8_t *>(h->st_q8.need(nqd));
+	int32_t *d_ids = static_cast<int32_t *>(h->st_ids.need((size_t)nq * kk * 4));
+	int32_t *d_val = static_cast<int32_t *>(h->st_dist.need((size_t)nq * kk * 4));
+	int32_t *d_cnt = static_cast<int32_t *>(h->st_cnt.need((size_t)nq * 4));
+	if (!d_q || !d_ids || !d_val || !d_cnt) {
+		h->set_error("out of device memory (scan staging)");
+		return 0;
+	}
+	HIP_OK(h, hipMemcpy(d_q, q, nqd, hipMemcpyHostToDevice));
+	if (!mvdb_scan_many_dev(h, d_q, nq, k, metric, d_ids, d_val, d_cnt, nullptr)) return 0;
+	HIP_OK(h, hipDeviceSynchronize());
+	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+	if (k > 0) {
+		HIP_OK(h, hipMemcpy(out_ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+		HIP_OK(h, hipMemcpy(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+	}
+	return 1;
+}
+
+int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2, const int32_t *d_n, int parts, int nq,
+                        int topk, int32_t *d_out_ids, double *d_out_l2, int32_t *d_out_n, void *stream)
+{
+	if (!ensure_device(h)) return 0;
+	if (nq <= 0) return 1;
+	if (parts > 64 || parts < 1) {
+		h->set_error("merge: parts must be 1..64");
+		return 0;
+	}
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	hipLaunchKernelGGL(merge_topk_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_ids, d_l2, d_n, parts, nq, topk,
+	                   d_out_ids, d_out_l2, d_out_n);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }
+float mvdb_last_stage_ms(mvdb_index *h, int stage)
+{
+	if (stage < 0 || stage > 3) return -1.f;
+	if (h->ev_pending[stage]) {
+		h->ev_pending[stage] = false;
+		float ms = -1.f;
+		if (hipEventSynchronize(h->ev1[stage]) == hipSuccess &&
+		    hipEventElapsedTime(&ms, h->ev0[stage], h->ev1[stage]) == hipSuccess)
+			h->stage_ms[stage] = ms;
+	}
+	return h->stage_ms[stage];
+}
+
+}  // extern "C"

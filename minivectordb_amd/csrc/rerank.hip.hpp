@@ -1,0 +1,289 @@
+// rerank.hip.hpp -- float32 exact-L2 rerank fused with a wave-shuffle top-k, plus query prep.
+//
+// Replaces the host loops of src/mini-vector-db.ts:
+//   normalizeF32InPlace :963-970, quantizeToI8 :972-984   -> prep_kernel
+//   candidate filter :606-621, l2SqF32 :986-993, sort (l2,id) + cut :626-651 -> rerank_kernel
+// The reference accumulates in JS doubles, strictly in element order.  To be bit-identical
+// (so the final topK ids are ALWAYS the reference's, ties included) every candidate's sum is
+// formed by ONE lane in element order with separate f64 multiply and add (no FMA contraction).
+// Rows are still fetched coalesced: a wave gathers 64 rows x 128 B per step (8 lanes x 16 B per
+// row), transposes the tile through padded LDS, and each lane then walks its own row.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "mvdb_hip.h"
+
+namespace mvdb {
+
+constexpr int kRerankThreads = 256;
+constexpr int kRerankWaves = kRerankThreads / 64;
+constexpr int kTileCols = 32;                    // floats per row per step (128 B)
+constexpr int kTileRowBytes = kTileCols * 4 + 16;  // 144-B padded rows: conflict-free b128 reads
+constexpr int kMaxTopK = 256;
+
+struct RerankArgs {
+	const float *q;           // nq x dim (already normalised)
+	const float *base;        // rows x dim (HBM or pinned host)
+	int64_t rows;
+	int dim, nq;
+	const int32_t *cand;      // nq x stride, ANN order
+	const int32_t *cand_count;  // nq
+	int stride, ann_k, topk;
+	const uint32_t *allow;    // bitmap over ids or null
+	int32_t *out_ids;         // nq x topk
+	double *out_l2;           // nq x topk
+	int32_t *out_n;           // nq
+};
+
+// LDS: q_s[dim_pad] f32 | tiles[kRerankWaves][64*144] | key_l2[cap] f64 | key_id[cap] i32 | misc
+__host__ __device__ inline size_t rerank_lds_bytes(int dim, int cap)
+{
+	size_t dim_pad = ((size_t)dim + kTileCols - 1) / kTileCols * kTileCols;
+	size_t b = dim_pad * 4;
+	b += (size_t)kRerankWaves * 64 * kTileRowBytes;
+	b = (b + 7) & ~(size_t)7;
+	b += (size_t)cap * 8 + (size_t)cap * 4;
+	b += 64 * 8 + 64 * 4 + 64;  // cross-wave reduction scratch + counters
+	return b;
+}
+
+struct KeyPair {
+	double l2;
+	int id;
+};
+__device__ __forceinline__ bool key_less(double al2, int aid, double bl2, int bid)
+{
+	return al2 < bl2 || (al2 == bl2 && aid < bid);  // :637  a.l2 - b.l2 || a.id - b.id
+}
+
+__global__ __launch_bounds__(kRerankThreads) void rerank_kernel(RerankArgs a, int cap)
+{
+#pragma clang fp contract(off)
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int qi = blockIdx.x;
+	const int dim = a.dim;
+	const int dim_pad = (dim + kTileCols - 1) / kTileCols * kTileCols;
+
+	float *q_s = reinterpret_cast<float *>(lds_raw);
+	unsigned char *tile = lds_raw + (size_t)dim_pad * 4 + (size_t)wave * 64 * kTileRowBytes;
+	size_t off = (size_t)dim_pad * 4 + (size_t)kRerankWaves * 64 * kTileRowBytes;
+	off = (off + 7) & ~(size_t)7;
+	double *key_l2 = reinterpret_cast<double *>(lds_raw + off);
+	int *key_id = reinterpret_cast<int *>(lds_raw + off + (size_t)cap * 8);
+	double *red_l2 = reinterpret_cast<double *>(lds_raw + off + (size_t)cap * 12);
+	int *red_id = reinterpret_cast<int *>(red_l2 + 64);
+	int *misc = red_id + 64;
+
+	for (int i = tid; i < dim_pad; i += kRerankThreads) q_s[i] = i < dim ? a.q[(size_t)qi * dim + i] : 0.f;
+
+	// ---- filter in ANN order, keep at most ann_k (:606-621); compact kept ids into key_id[]
+	int cc = a.cand_count[qi];
+	if (cc > a.stride) cc = a.stride;
+	if (tid == 0) misc[0] = 0;
+	__syncthreads();
+	const int32_t *cq = a.cand + (size_t)qi * a.stride;
+	for (int base = 0; base < cc; base += kRerankThreads) {
+		const int j = base + tid;
+		int id = -1;
+		bool keep = false;
+		if (j < cc) {
+			id = cq[j];
+			keep = true;
+			if (a.allow) keep = id >= 0 && ((a.allow[(unsigned)id >> 5] >> (id & 31)) & 1u);
+		}
+		// ordered compaction across the block: per-wave ballot + wave offsets
+		const unsigned long long m = __ballot(keep);
+		if (lane == 0) misc[1 + wave] = __builtin_popcountll(m);
+		__syncthreads();
+		int before = misc[0];
+		for (int w = 0; w < wave; w++) before += misc[1 + w];
+		const int pos = before + __builtin_popcountll(m & ((1ull << lane) - 1));
+		if (keep && pos < a.ann_k) key_id[pos] = id;
+		__syncthreads();
+		if (tid == 0) {
+			int tot = misc[0];
+			for (int w = 0; w < kRerankWaves; w++) tot += misc[1 + w];
+			misc[0] = tot;
+		}
+		__syncthreads();
+	}
+	int nkept = misc[0];
+	if (nkept > a.ann_k) nkept = a.ann_k;
+
+	// ---- exact f64 L2^2 per candidate; each wave owns groups of 64 candidates
+	const int g = lane >> 3, s = lane & 7;
+	for (int c0 = wave * 64; c0 < nkept; c0 += kRerankWaves * 64) {
+		const int my = c0 + lane;
+		const int my_id = my < nkept ? key_id[my] : -1;
+		const bool my_ok = my_id >= 0 && (int64_t)my_id < a.rows;  // rows beyond the store are skipped (:1090)
+		double acc = 0.0;
+		for (int col = 0; col < dim_pad; col += kTileCols) {
+			// gather: pass p brings rows p*8+g, 16 B at column piece s
+#pragma unroll
+			for (int p = 0; p < 8; p++) {
+				const int r = p * 8 + g;
+				const int rid = __shfl(my_id, r);
+				const bool ok = __shfl((int)my_ok, r);
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				const int e = col + s * 4;
+				if (ok && e < dim) {
+					const float *src = a.base + (size_t)rid * (size_t)dim + e;
+					if (e + 4 <= dim) v = *reinterpret_cast<const float4 *>(src);
+					else {
+						v.x = src[0];
+						if (e + 1 < dim) v.y = src[1];
+						if (e + 2 < dim) v.z = src[2];
+					}
+				}
+				*reinterpret_cast<float4 *>(tile + r * kTileRowBytes + s * 16) = v;
+			}
+			// each lane walks its own row in element order (sequential f64, :987-991)
+#pragma unroll
+			for (int c = 0; c < kTileCols / 4; c++) {
+				const float4 v = *reinterpret_cast<const float4 *>(tile + lane * kTileRowBytes + c * 16);
+				const float4 qv = *reinterpret_cast<const float4 *>(q_s + col + c * 4);
+				const int e = col + c * 4;
+				if (e < dim) {
+					double d = (double)qv.x - (double)v.x;
+					acc = acc + d * d;
+				}
+				if (e + 1 < dim) {
+					double d = (double)qv.y - (double)v.y;
+					acc = acc + d * d;
+				}
+				if (e + 2 < dim) {
+					double d = (double)qv.z - (double)v.z;
+					acc = acc + d * d;
+				}
+				if (e + 3 < dim) {
+					double d = (double)qv.w - (double)v.w;
+					acc = acc + d * d;
+				}
+			}
+		}
+		if (my < nkept) {
+			key_l2[my] = my_ok ? acc : __builtin_inf();
+			if (!my_ok) key_id[my] = 0x7fffffff;  // dropped candidate
+		}
+	}
+	__syncthreads();
+
+	// ---- top-k by (l2, id): k rounds of block-wide arg-min (wave shuffles + one LDS hop)
+	int emitted = 0;
+	for (int round = 0; round < a.topk; round++) {
+		double bl2 = __builtin_inf();
+		int bid = 0x7fffffff, bpos = -1;
+		for (int j = tid; j < nkept; j += kRerankThreads) {
+			const double l = key_l2[j];
+			const int id = key_id[j];
+			if (id != 0x7fffffff && (bpos < 0 || key_less(l, id, bl2, bid))) {
+				bl2 = l;
+				bid = id;
+				bpos = j;
+			}
+		}
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) {
+			const double ol2 = __shfl_xor(bl2, o);
+			const int oid = __shfl_xor(bid, o);
+			const int opos = __shfl_xor(bpos, o);
+			if (opos >= 0 && (bpos < 0 || key_less(ol2, oid, bl2, bid))) {
+				bl2 = ol2;
+				bid = oid;
+				bpos = opos;
+			}
+		}
+		if (lane == 0) {
+			red_l2[wave] = bl2;
+			red_id[wave] = bid;
+			red_id[8 + wave] = bpos;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			double wl2 = red_l2[0];
+			int wid = red_id[0], wpos = red_id[8];
+			for (int w = 1; w < kRerankWaves; w++) {
+				const int p = red_id[8 + w];
+				if (p >= 0 && (wpos < 0 || key_less(red_l2[w], red_id[w], wl2, wid))) {
+					wl2 = red_l2[w];
+					wid = red_id[w];
+					wpos = p;
+				}
+			}
+			misc[8] = wpos;
+			if (wpos >= 0) {
+				a.out_ids[(size_t)qi * a.topk + round] = wid;
+				a.out_l2[(size_t)qi * a.topk + round] = wl2;
+				key_id[wpos] = 0x7fffffff;  // consumed
+			}
+		}
+		__syncthreads();
+		if (misc[8] < 0) break;
+		emitted++;
+	}
+	if (tid == 0) a.out_n[qi] = emitted;
+}
+
+// ---- query prep: normalizeF32InPlace + quantizeToI8, one lane per query ---------------
+__global__ void prep_kernel(const float *q_in, int nq, int dim, float *q_norm, int8_t *q_i8)
+{
+#pragma clang fp contract(off)
+	const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (qi >= nq) return;
+	const float *src = q_in + (size_t)qi * dim;
+	double normSq = 0.0;
+	for (int i = 0; i < dim; i++) {  // :964-965 strictly sequential f64
+		const double x = (double)src[i];
+		normSq = normSq + x * x;
+	}
+	const bool scale = !(normSq <= 0.0);   // :966 (NaN norm falls through, as in JS)
+	const double inv = 1.0 / sqrt(normSq);  // :967
+	for (int i = 0; i < dim; i++) {
+		float v = src[i];
+		if (scale) v = (float)((double)v * inv);  // :968 f64 product rounded to f32 on store
+		if (q_norm) q_norm[(size_t)qi * dim + i] = v;
+		if (q_i8) {  // :974-981
+			double x = (double)v;
+			if (x > 1.0) x = 1.0;
+			else if (x < -1.0) x = -1.0;
+			double r = floor(x * 127.0 + 0.5);  // Math.round: ties toward +inf
+			if (r > 127.0) r = 127.0;
+			else if (r < -127.0) r = -127.0;
+			q_i8[(size_t)qi * dim + i] = (r != r) ? (int8_t)0 : (int8_t)(int)r;
+		}
+	}
+}
+
+// ---- merge of per-shard top-k lists: one thread per query ------------------
+__global__ void merge_topk_kernel(const int32_t *ids, const double *l2, const int32_t *n, int parts, int nq,
+                                  int topk, int32_t *out_ids, double *out_l2, int32_t *out_n)
+{
+	const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (qi >= nq) return;
+	int head[64];
+	for (int p = 0; p < parts; p++) head[p] = 0;
+	int emitted = 0;
+	for (; emitted < topk; emitted++) {
+		int bp = -1;
+		double bl = 0;
+		int bi = 0;
+		for (int p = 0; p < parts; p++) {
+			if (head[p] >= n[(size_t)p * nq + qi]) continue;
+			const size_t o = ((size_t)p * nq + qi) * topk + head[p];
+			if (bp < 0 || key_less(l2[o], ids[o], bl, bi)) {
+				bp = p;
+				bl = l2[o];
+				bi = ids[o];
+			}
+		}
+		if (bp < 0) break;
+		head[bp]++;
+		out_ids[(size_t)qi * topk + emitted] = bi;
+		out_l2[(size_t)qi * topk + emitted] = bl;
+	}
+	out_n[qi] = emitted;
+}
+
+}  // namespace mvdb

@@ -1,0 +1,148 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: int8 distances and HNSW candidate (id, dist) lists bit-exact; float32 rerank L2 bit-exact in
+f64 (stricter than the 1e-5 relative the north star allows) with identical topK ids.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests._data import bridge_from_dump, built_index, gaussian_unit, oracle_from_dump
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(gpu):
+    dump, base, b8 = built_index(4000, 384, "balanced")
+    return dump, base, b8
+
+
+def _check_lists(b, ix, q8, k, ef):
+    b.setEfSearch(ef)
+    ix.set_ef_search(ef)
+    ids, dist, cnt, ctr = b.searchManyArrays(q8, k, with_counters=True)
+    oi, od, oc, octr = ix.search_many(q8, k, threads=8)
+    assert np.array_equal(cnt, oc)
+    for qi in range(len(cnt)):
+        n = cnt[qi]
+        assert np.array_equal(ids[qi, :n], oi[qi, :n]), f"query {qi}: candidate id list differs"
+        assert np.array_equal(dist[qi, :n].view(np.uint32), od[qi, :n].view(np.uint32)), f"query {qi}: dist differs"
+    assert np.array_equal(ctr[:, 0], octr["n_dist"])
+    assert np.array_equal(ctr[:, 1], octr["n_l0lists"])
+    assert np.array_equal(ctr[:, 2], octr["n_upperlists"])
+    return ids, cnt
+
+
+def test_search_many_bit_exact_balanced(small):
+    dump, base, b8 = small
+    b = bridge_from_dump(dump, 384, "balanced")
+    ix = oracle_from_dump(dump, 384, "balanced")
+    b.setResultsCap(4096)
+    ix.set_results_cap(4096)
+    q8 = O.quantize_rows_i8(gaussian_unit(96, 384, 54321))
+    _check_lists(b, ix, q8, 1200, 140)      # balanced: ef = annK = 1200
+    _check_lists(b, ix, q8[:32], 10, 50)    # small ef, k < ef
+    _check_lists(b, ix, q8[:16], 4096, 20)  # clamp: ef = k = MAX_EF
+    _check_lists(b, ix, q8[:8], 5000, 20)   # k > MAX_EF -> ef clamped, flag raised
+    assert b._L.mvdb_was_ef_clamped(b.handle) == 1
+
+
+def test_prepare_queries_bit_exact(gpu):
+    from minivectordb_amd import HipBridge
+    b = HipBridge()
+    b.init(dict(dim=384, m=16, ef=300, capacity=4, seed=1))
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((257, 384)).astype(np.float32) * rng.uniform(1e-3, 50, (257, 1)).astype(np.float32)
+    q[3] = 0                       # zero vector passes through un-normalised (:966)
+    q[4, :] = 0; q[4, 7] = 1       # one-hot
+    q[5] = np.float32(1e-30)       # underflowing norm
+    q[6, 0] = np.float32(3e38)     # norm overflows to inf -> all zero after scaling
+    qn, qi = b.prepareQueries(q)
+    on = O.normalize_rows_f32(q)
+    assert np.array_equal(qn.view(np.uint32), on.view(np.uint32))
+    assert np.array_equal(qi, O.quantize_rows_i8(on))
+
+
+def test_rerank_bit_exact(small):
+    dump, base, b8 = small
+    b = bridge_from_dump(dump, 384, "balanced")
+    ix = oracle_from_dump(dump, 384, "balanced")
+    b.setResultsCap(4096); ix.set_results_cap(4096)
+    b.setEfSearch(140); ix.set_ef_search(140)
+    qf = gaussian_unit(64, 384, 999)
+    q8 = O.quantize_rows_i8(qf)
+    ids, dist, cnt = b.searchManyArrays(q8, 1200)
+    b.attachF32(base, resident=True)
+    # no filter
+    gi, gl, gn = b.rerankMany(qf, ids, cnt, 1200, 10)
+    oi, ol, on = O.rerank_many(qf, base, ids, cnt, 1200, 10)
+    assert np.array_equal(gn, on) and np.array_equal(gi, oi)
+    assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))       # f64 bit-exact
+    # allow bitmap (deleted / filter), ann_k cap smaller than the list, ragged counts, short store
+    rng = np.random.default_rng(3)
+    allow = rng.integers(0, 2**32, (4000 + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    cnt2 = cnt.copy(); cnt2[::3] = 7; cnt2[1] = 0
+    gi, gl, gn = b.rerankMany(qf, ids, cnt2, 300, 17, allow)
+    oi, ol, on = O.rerank_many(qf, base, ids, cnt2, 300, 17, allow)
+    assert np.array_equal(gn, on) and np.array_equal(gi, oi)
+    assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
+    b.attachF32(base[:2500], resident=False)                            # ids beyond the store are skipped
+    gi, gl, gn = b.rerankMany(qf, ids, cnt, 1200, 10)
+    oi, ol, on = O.rerank_many(qf, base[:2500], ids, cnt, 1200, 10)
+    assert np.array_equal(gn, on) and np.array_equal(gi, oi)
+    assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
+
+
+def test_query_many_matches_reference_pipeline(small):
+    dump, base, b8 = small
+    b = bridge_from_dump(dump, 384, "balanced")
+    ix = oracle_from_dump(dump, 384, "balanced")
+    b.attachF32(base)
+    q = np.random.default_rng(11).standard_normal((80, 384)).astype(np.float32)   # un-normalised on purpose
+    tk, ef, ann_k = O.derive_search_params(10, "balanced")
+    gi, gl, gn, ctr = b.queryMany(q, tk, ef, ann_k, with_counters=True)
+    oi, ol, on, ann, acnt, octr = O.search_many_db(ix, q, base, 10, "balanced", threads=8)
+    assert np.array_equal(gn, on) and np.array_equal(gi, oi)
+    assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
+    assert np.array_equal(ctr[:, 0], octr["n_dist"])
+
+
+def test_dist_many_bit_exact(small):
+    dump, base, b8 = small
+    b = bridge_from_dump(dump, 384, "balanced")
+    rng = np.random.default_rng(2)
+    q8 = rng.integers(-127, 128, (33, 384)).astype(np.int8)
+    ids = rng.integers(0, 4000, (33, 50)).astype(np.int32)
+    ids[0, 0] = -1
+    for metric, fn in (("l2", O.dist_l2_i8), ("dot", O.dot_i8)):
+        out = b.distMany(q8, ids, metric)
+        for qi in range(33):
+            for j in range(50):
+                exp = fn(q8[qi], b8[ids[qi, j]]) if ids[qi, j] >= 0 else -2**31
+                assert out[qi, j] == exp
+
+
+@pytest.mark.parametrize("dim,preset,n", [(512, "accurate", 1500), (64, "fast", 2000), (100, "fast", 700)])
+def test_other_dims_and_presets(gpu, dim, preset, n):
+    dump, base, b8 = built_index(n, dim, preset)
+    b = bridge_from_dump(dump, dim, preset)
+    ix = oracle_from_dump(dump, dim, preset)
+    b.setResultsCap(4096); ix.set_results_cap(4096)
+    q8 = O.quantize_rows_i8(gaussian_unit(40, dim, 54321))
+    tk, ef, ann_k = O.derive_search_params(10, preset)
+    _check_lists(b, ix, q8, ann_k, ef)
+
+
+def test_scan_many_bit_exact(small):
+    dump, base, b8 = small
+    b = bridge_from_dump(dump, 384, "balanced")
+    ix = oracle_from_dump(dump, 384, "balanced")
+    q8 = O.quantize_rows_i8(gaussian_unit(300, 384, 77))
+    for metric in ("l2", "dot"):
+        for k in (1, 10, 32):
+            gi, gv, gc = b.scanMany(q8, k, metric)
+            oi, ov, oc = ix.scan_many(q8, k, metric, threads=8)
+            assert np.array_equal(gc, oc)
+            assert np.array_equal(gi, oi), (metric, k)
+            assert np.array_equal(gv, ov), (metric, k)
