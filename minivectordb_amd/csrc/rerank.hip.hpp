@@ -224,6 +224,10 @@ __global__ __launch_bounds__(kRerankThreads) void rerank_kernel(RerankArgs a, in
 		emitted++;
 	}
 	if (tid == 0) a.out_n[qi] = emitted;
+	for (int j = emitted + tid; j < a.topk; j += kRerankThreads) {  // deterministic tail
+		a.out_ids[(size_t)qi * a.topk + j] = -1;
+		a.out_l2[(size_t)qi * a.topk + j] = 0.0;
+	}
 }
 
 // ---- query prep: normalizeF32InPlace + quantizeToI8, one lane per query ---------------

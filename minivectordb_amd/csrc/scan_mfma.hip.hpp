@@ -304,6 +304,10 @@ __global__ void scan_merge_kernel(ScanArgs a)
 		a.out_val[(size_t)qi * a.k + out] = a.metric == 0 ? val : -val;
 	}
 	a.out_count[qi] = out;
+	for (int i = out; i < a.k; i++) {  // deterministic tail
+		a.out_ids[(size_t)qi * a.k + i] = -1;
+		a.out_val[(size_t)qi * a.k + i] = 0;
+	}
 }
 
 template <int KS>

@@ -369,6 +369,10 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 		a.out_ids[(size_t)qi * (size_t)a.k + i] = cand_i[i];
 		a.out_dist[(size_t)qi * (size_t)a.k + i] = cand_d[i];
 	}
+	for (int i = out_count + lane; i < a.k; i += 64) {  // deterministic tail of a ragged row
+		a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
+		a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
+	}
 	if (lane == 0) {
 		a.out_count[qi] = out_count;
 		if (a.ctr) {
