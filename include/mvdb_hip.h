@@ -179,6 +179,9 @@ int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2,
  * 1 traversal, 2 rerank, 3 scan. Returns <0 when no sample exists. */
 void mvdb_enable_timing(mvdb_index *h, int on);
 float mvdb_last_stage_ms(mvdb_index *h, int stage);
+/* launches and summed device ms of a stage since the last reset (one HIP event pair
+ * per launch, resolved here, never inside the caller's timed region) */
+int mvdb_stage_stats(mvdb_index *h, int stage, long long *launches, double *total_ms, int reset);
 
 #ifdef __cplusplus
 }

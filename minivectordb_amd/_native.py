@@ -65,6 +65,7 @@ SYMBOLS = [
     ("mvdb_merge_topk_dev", _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_enable_timing", None, [_vp, _i]),
     ("mvdb_last_stage_ms", _f, [_vp, _i]),
+    ("mvdb_stage_stats", _i, [_vp, _i, _vp, _vp, _i]),
 ]
 
 _lib = None

@@ -198,19 +198,21 @@ struct mvdb_index {
 		st_misc, scan_part;
 
 	bool timing = false;
-	hipEvent_t ev0[4] = {nullptr, nullptr, nullptr, nullptr}, ev1[4] = {nullptr, nullptr, nullptr, nullptr};
-	bool ev_pending[4] = {false, false, false, false};
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[4];
 	float stage_ms[4] = {-1.f, -1.f, -1.f, -1.f};
+	double stage_total_ms[4] = {0, 0, 0, 0};
+	long long stage_count[4] = {0, 0, 0, 0};
 
 	void set_error(const std::string &s) { err = s; }
 	~mvdb_index()
 	{
 		(void)hipFree(f32_dev);
 		if (f32_pinned) (void)hipHostFree(f32_pinned);
-		for (int i = 0; i < 4; i++) {
-			if (ev0[i]) (void)hipEventDestroy(ev0[i]);
-			if (ev1[i]) (void)hipEventDestroy(ev1[i]);
-		}
+		for (auto &v : ev_pairs)
+			for (auto &pr : v) {
+				(void)hipEventDestroy(pr.first);
+				(void)hipEventDestroy(pr.second);
+			}
 	}
 };
 
@@ -253,27 +255,45 @@ int ensure_uploaded(mvdb_index *h)
 	return 1;
 }
 
-// device time of a stage: HIP events recorded on the launching stream; read lazily
+// device time of a stage: one HIP event pair per launch, recorded on the launching stream
+// and resolved lazily (no synchronisation inside the timed region)
 struct StageTimer {
 	mvdb_index *h;
 	int stage;
 	hipStream_t s;
+	hipEvent_t e1 = nullptr;
 	StageTimer(mvdb_index *h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_)
 	{
 		if (!h->timing) return;
-		if (!h->ev0[stage]) {
-			(void)hipEventCreate(&h->ev0[stage]);
-			(void)hipEventCreate(&h->ev1[stage]);
+		hipEvent_t e0 = nullptr;
+		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+			e1 = nullptr;
+			return;
 		}
-		(void)hipEventRecord(h->ev0[stage], s);
+		(void)hipEventRecord(e0, s);
+		h->ev_pairs[stage].emplace_back(e0, e1);
 	}
 	~StageTimer()
 	{
-		if (!h->timing) return;
-		(void)hipEventRecord(h->ev1[stage], s);
-		h->ev_pending[stage] = true;
+		if (e1) (void)hipEventRecord(e1, s);
 	}
 };
+
+void resolve_stage(mvdb_index *h, int stage)
+{
+	for (auto &pr : h->ev_pairs[stage]) {
+		float ms = 0.f;
+		if (hipEventSynchronize(pr.second) == hipSuccess &&
+		    hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+			h->stage_ms[stage] = ms;
+			h->stage_total_ms[stage] += ms;
+			h->stage_count[stage]++;
+		}
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
+	}
+	h->ev_pairs[stage].clear();
+}
 
 template <int J, bool FULL>
 int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
@@ -503,10 +523,10 @@ int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		h->set_error("out of device memory (visited bitmaps)");
 		return 0;
 	}
-	StageTimer t(h, 1, s);
 	for (int q0 = 0; q0 < nq; q0 += slab) {
 		const int n = std::min(slab, nq - q0);
 		HIP_OK(h, hipMemsetAsync(vis, 0, (size_t)n * a.vis_words * 4, s));
+		StageTimer t(h, 1, s);  // brackets the traversal kernel only
 		a.q = d_q + (size_t)q0 * g.cfg.dim;
 		a.nq = n;
 		a.visited = vis;
@@ -868,14 +888,20 @@ void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }
 float mvdb_last_stage_ms(mvdb_index *h, int stage)
 {
 	if (stage < 0 || stage > 3) return -1.f;
-	if (h->ev_pending[stage]) {
-		h->ev_pending[stage] = false;
-		float ms = -1.f;
-		if (hipEventSynchronize(h->ev1[stage]) == hipSuccess &&
-		    hipEventElapsedTime(&ms, h->ev0[stage], h->ev1[stage]) == hipSuccess)
-			h->stage_ms[stage] = ms;
-	}
+	resolve_stage(h, stage);
 	return h->stage_ms[stage];
+}
+int mvdb_stage_stats(mvdb_index *h, int stage, long long *launches, double *total_ms, int reset)
+{
+	if (stage < 0 || stage > 3) return 0;
+	resolve_stage(h, stage);
+	if (launches) *launches = h->stage_count[stage];
+	if (total_ms) *total_ms = h->stage_total_ms[stage];
+	if (reset) {
+		h->stage_count[stage] = 0;
+		h->stage_total_ms[stage] = 0;
+	}
+	return 1;
 }
 
 }  // extern "C"
