@@ -195,7 +195,7 @@ struct mvdb_index {
 
 	// scratch
 	DevBuf visited, st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
-		st_misc, scan_part;
+		st_misc, scan_part, prof_buf;
 
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[4];
@@ -534,6 +534,10 @@ int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		a.out_dist = d_out_dist + (size_t)q0 * k;
 		a.out_count = d_out_count + q0;
 		a.ctr = d_ctr ? d_ctr + q0 : nullptr;
+		a.prof = nullptr;
+#ifdef MVDB_TRAVERSE_PROFILE
+		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 64)) + (size_t)q0 * 8;
+#endif
 		if (!launch_traverse(h, a, s)) return 0;
 	}
 	return 1;
@@ -884,6 +888,14 @@ int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2,
 	return 1;
 }
 
+#ifdef MVDB_TRAVERSE_PROFILE
+// diagnostic build only: per-query cycle sums of the last traversal launch (nq x 8)
+int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
+{
+	if (!h->prof_buf.p) return 0;
+	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 64, hipMemcpyDeviceToHost) == hipSuccess;
+}
+#endif
 void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }
 float mvdb_last_stage_ms(mvdb_index *h, int stage)
 {

@@ -26,6 +26,17 @@ __device__ __forceinline__ float rfl(float v)
 	return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
+// one ds_read_b128 (hipcc otherwise splits the read and sinks half of it behind the branch,
+// which costs a second dependent LDS round trip per heap level)
+__device__ __forceinline__ uint4 lds_read16(const void *p)
+{
+	using u4 = __attribute__((ext_vector_type(4))) unsigned;
+	u4 v;
+	const unsigned addr = (unsigned)(size_t)p;  // low 32 bits of a shared pointer = LDS byte offset
+	asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // sum over each aligned group of 8 lanes, result in all 8 lanes (DPP only, no LDS)
 __device__ __forceinline__ int reduce8(int x)
 {
@@ -35,80 +46,140 @@ __device__ __forceinline__ int reduce8(int x)
 	return x;
 }
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
+typedef __attribute__((address_space(3))) u32x2_t lds_u32x2;
+
 // ---- 1-based array heaps in LDS ------------------------------------------------
 // MIN = candidate min-heap (hnsw.ts:153-213), !MIN = result max-heap (:233-315).
+// Entry p = {key, id} (8 bytes); children 2p, 2p+1 are one aligned 16-byte LDS read.
+// key = bit pattern of the f32 distance (math.ts:126 <f32> cast).  Distances are >= 0, so
+// unsigned integer order of the bit patterns == the reference's f32 order, and every heap
+// decision runs on the scalar unit (readfirstlane -> s_cmp -> s_cbranch), not under EXEC masks.
 template <bool MIN>
 struct LdsHeap {
-	float *d;  // d[1..size]
-	int *id;
+	uint2 *h;           // h[1..size]
+	unsigned lds_base;  // LDS byte offset of h[0]
 
-	static __device__ __forceinline__ bool stops(float parent, float child)
+	static __device__ __forceinline__ bool stops(unsigned parent, unsigned child)
 	{
 		return MIN ? parent <= child : parent >= child;  // :163 / :243, :206 / :283
 	}
-	// push (nid, nd) into a heap of `size`; one parallel sift-up.  Lane j looks at
-	// ancestor j+1 of the new slot; ancestors below the stopping one shift down a level.
-	__device__ __forceinline__ void push(int size, int nid, float nd, int lane) const
+	// push (nid, nkey) into a heap of `size`; one parallel sift-up.  Lane j looks at ancestor
+	// j+1 of the new slot; ancestors below the stopping one shift down a level.  Branch-free:
+	// lanes with nothing to do read and rewrite entry 0, which the 1-based layout never uses.
+	__device__ __forceinline__ void push(int size, int nid, unsigned nkey, int lane) const
 	{
-		const int pos = size + 1;
-		const int anc = lane < 16 ? (pos >> (lane + 1)) : 0;
-		float ad = 0.f;
-		int aid = 0;
-		if (anc >= 1) {
-			ad = d[anc];
-			aid = id[anc];
-		}
-		const bool stop = anc < 1 || stops(ad, nd);
+		const unsigned pos = (unsigned)rfl(size) + 1u;
+		const unsigned sh = lane < 31 ? (unsigned)lane : 31u;
+		const unsigned self = pos >> sh, anc = self >> 1;
+		const u32x2_t e = *reinterpret_cast<const lds_u32x2 *>((size_t)(lds_base + anc * 8u));
+		const bool stop = anc == 0u || stops(e.x, nkey);
 		const int J = __builtin_ctzll(__ballot(stop));
-		if (lane < J) {
-			d[pos >> lane] = ad;
-			id[pos >> lane] = aid;
-		}
-		if (lane == J) {
-			d[pos >> J] = nd;
-			id[pos >> J] = nid;
-		}
+		const u32x2_t mine = {nkey, (unsigned)nid};
+		const u32x2_t w = lane == J ? mine : e;
+		*reinterpret_cast<lds_u32x2 *>((size_t)(lds_base + (lane <= J ? self * 8u : 0u))) = w;
 	}
-	// place (nid, nd) at the root of a heap of `size` and sift down (:191-210, :268-287)
-	__device__ __forceinline__ void sift_root(int size, int nid, float nd, int lane) const
+	// place (nid, nkey) at the root of a heap of `size` and sift down (:191-210, :268-287)
+	__device__ __forceinline__ void sift_root(int size, int nid, unsigned nkey, int lane) const
 	{
+		size = rfl(size);  // keep the whole walk on the scalar unit
+		nkey = (unsigned)rfl((int)nkey);
 		int p = 1;
 		for (;;) {
 			const int l = 2 * p;
 			if (l > size) break;
-			const float2 ch = *reinterpret_cast<const float2 *>(d + l);  // children l, l+1
-			float dl = rfl(ch.x), dr = rfl(ch.y);
-			int c = l;
-			float dc = dl;
-			if (l + 1 <= size && (MIN ? dr < dl : dr > dl)) {  // :201 / :278 right only if strictly better
-				c = l + 1;
-				dc = dr;
-			}
-			if (stops(nd, dc)) break;
-			const int cid = id[c];
-			if (lane == 0) {
-				d[p] = dc;
-				id[p] = cid;
-			}
-			p = c;
+			// {key_l, id_l, key_r, id_r}: entry l is 16-byte aligned (l even, base 16-byte aligned)
+			const uint4 ch = lds_read16(h + l);
+			const unsigned kl = (unsigned)rfl((int)ch.x), kr = (unsigned)rfl((int)ch.z);
+			// :201 / :278 the right child only if strictly better
+			const bool right = (l + 1 <= size) && (MIN ? kr < kl : kr > kl);
+			const unsigned kc = right ? kr : kl;
+			if (stops(nkey, kc)) break;
+			const uint2 moved = right ? make_uint2(ch.z, ch.w) : make_uint2(ch.x, ch.y);
+			if (lane == 0) h[p] = moved;
+			p = l + (right ? 1 : 0);
 		}
-		if (lane == 0) {
-			d[p] = nd;
-			id[p] = nid;
-		}
+		if (lane == 0) h[p] = make_uint2(nkey, (unsigned)nid);
 	}
-	// pop the root; returns new size.  (rid, rd) = old root.
-	__device__ __forceinline__ int pop(int size, int &rid, float &rd, int lane) const
+	// pop the root; returns new size.  (rid, rkey) = old root.
+	__device__ __forceinline__ int pop(int size, int &rid, unsigned &rkey, int lane) const
 	{
-		rid = rfl(id[1]);
-		rd = rfl(d[1]);
-		size--;
+		const uint2 root = h[1];
+		rkey = (unsigned)rfl((int)root.x);
+		rid = rfl((int)root.y);
+		size = rfl(size) - 1;
 		if (size > 0) {
-			const int lid = rfl(id[size + 1]);
-			const float ld = rfl(d[size + 1]);
-			sift_root(size, lid, ld, lane);
+			const uint2 last = h[size + 1];
+			sift_root(size, rfl((int)last.y), (unsigned)rfl((int)last.x), lane);
 		}
 		return size;
+	}
+};
+
+// ---- pipelined sift-downs ----------------------------------------------------------
+// replace_root (:291-315) and pop (:173-213, :250-289) walk root->leaf one level per step and only
+// ever move entries UP along their own path.  Several of them can therefore be in flight at once,
+// one per lane, each one level further down per tick, provided a younger operation never reads
+// a slot an older one still has to write: the younger one takes a step at level L only when
+// every older one is at level >= L+2 (or done).  The resulting array is bit-identical to running
+// the operations one after another, at two ticks per operation instead of ~log2(ef) dependent
+// LDS round trips, and ticks can be spent while global loads are in flight.  A pop also carries
+// the heap's LAST entry to the root; it may be issued only when no operation in flight sits on
+// the root->last-slot chain (it could still rewrite that slot).
+
+template <bool MIN>
+struct HeapPipe {
+	unsigned base = 0;  // LDS byte offset of entry 0 of the heap (16-byte aligned)
+	unsigned a = 0;     // this lane's operation: 8 * position, 0 = idle
+	unsigned lim = 0;   // 8 * heap size the operation works in
+	unsigned key = 0, id = 0;
+	unsigned root_key = 0;  // in the lane whose operation just took its root step: the new root key
+	int next_lane = 0;
+
+	__device__ __forceinline__ bool busy() const { return __ballot(a != 0) != 0; }
+	// an operation in flight is still at level 1 or 2 (positions 1..3)
+	__device__ __forceinline__ bool near_root() const { return __ballot(a != 0 && a < 32) != 0; }
+	__device__ __forceinline__ bool on_chain_to(int slot) const
+	{
+		const int pos = (int)(a >> 3);
+		const int lp = 31 - __builtin_clz(pos > 0 ? pos : 1), ls = 31 - __builtin_clz(slot);
+		const bool hit = pos > 0 && lp <= ls && (slot >> (ls - lp)) == pos;
+		return __ballot(hit) != 0;
+	}
+	// returns the lane that owns the new operation
+	__device__ __forceinline__ int issue(int lane, int heap_size, unsigned nkey, unsigned nid)
+	{
+		const int owner = next_lane;
+		if (lane == owner) {
+			a = 8;
+			lim = 8u * (unsigned)heap_size;
+			key = nkey;
+			id = nid;
+		}
+		next_lane = (next_lane + 1) & 15;
+		return owner;
+	}
+	// Every operation in flight moves one level (:191-210 / :295-314).  Branch-free: an idle lane
+	// (a == 0) reads and rewrites entry 0 of the heap, which the 1-based layout never uses.
+	__device__ __forceinline__ void tick()
+	{
+		const unsigned ca = a << 1;
+		const bool has_l = a != 0 && ca <= lim;
+		const u32x4_t ch = *reinterpret_cast<const lds_u32x4 *>((size_t)(base + (has_l ? ca : 0u)));
+		// :201 / :305 the right child only if strictly better
+		const bool right = (ca + 8 <= lim) && (MIN ? ch.z < ch.x : ch.z > ch.x);
+		const unsigned kc = right ? ch.z : ch.x, ic = right ? ch.w : ch.y;
+		const bool stop = !has_l || (MIN ? key <= kc : key >= kc);  // :206 / :310
+		const u32x2_t w = {stop ? key : kc, stop ? id : ic};
+		*reinterpret_cast<lds_u32x2 *>((size_t)(base + a)) = w;
+		root_key = a == 8 ? w.x : root_key;
+		a = stop ? 0u : ca + (right ? 8u : 0u);
+	}
+	__device__ __forceinline__ void drain()
+	{
+		while (busy()) tick();
 	}
 };
 
@@ -173,11 +244,11 @@ __device__ __forceinline__ void load_row(int4 (&v)[J], const DevIndexView &ix, i
 	}
 }
 
-// distances of rows ids_s[0..n) (LDS) -> dist_s[0..n) as f32 (math.ts:126 <f32> cast).
+// distances of rows ids_s[0..n) (LDS) -> dist_s[0..n): bit patterns of the f32 (math.ts:126 <f32> cast).
 // 8 rows per pass, 4 passes of loads in flight.
 template <int J, bool FULL>
 __device__ __forceinline__ void dist_rows(const DevIndexView &ix, const QueryRegs<J> &Q, const int *ids_s,
-                                          float *dist_s, int n, int safe_row, int lane)
+                                          unsigned *dist_s, int n, int safe_row, int lane)
 {
 	const int g = lane >> 3, s = lane & 7;
 	for (int p0 = 0; p0 < n; p0 += 32) {
@@ -193,7 +264,7 @@ __device__ __forceinline__ void dist_rows(const DevIndexView &ix, const QueryReg
 		for (int pp = 0; pp < 4; pp++) {
 			if (p0 + pp * 8 < n) {
 				const int tot = Q.qq + reduce8(row_partial<J>(Q, v[pp]));
-				if (s == 0 && slot[pp] < n) dist_s[slot[pp]] = (float)tot;
+				if (s == 0 && slot[pp] < n) dist_s[slot[pp]] = __float_as_uint((float)tot);
 			}
 		}
 	}
@@ -210,12 +281,26 @@ struct TraverseArgs {
 	float *out_dist;      // nq x k
 	int32_t *out_count;   // nq
 	mvdb_query_counters *ctr;  // nq or null
+	unsigned long long *prof;  // diagnostic builds only (MVDB_TRAVERSE_PROFILE): nq x 8 cycle sums
 };
 
-// LDS carve (dynamic): res_d[ef+2] res_i[ef+2] cand_d[cap+2] cand_i[cap+2] ids_s[64] dist_s[64] code_s[64]
+#ifdef MVDB_TRAVERSE_PROFILE
+#define MVDB_STAMP(slot)                                        \
+	do {                                                        \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+		prof_acc[slot] += now_ - prof_last;                     \
+		prof_last = now_;                                       \
+	} while (0)
+#else
+#define MVDB_STAMP(slot) \
+	do {                 \
+	} while (0)
+#endif
+
+// LDS carve (dynamic): res[ef+2] cand[cap+2] (8-byte entries, 16-byte aligned) ids_s[64] dist_s[64] code_s[64]
 __host__ __device__ inline size_t traverse_lds_bytes(int ef, int cand_cap)
 {
-	return (size_t)4 * (2 * (size_t)(ef + 2) + 2 * (size_t)(cand_cap + 2) + 3 * 64);
+	return (size_t)8 * (size_t)((ef + 3) & ~1) + (size_t)8 * (size_t)((cand_cap + 3) & ~1) + (size_t)4 * 3 * 64;
 }
 
 template <int J, bool FULL>
@@ -228,28 +313,30 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 	const DevIndexView &ix = a.ix;
 
 	const int ef = a.ef, cand_cap = a.cand_cap;
-	float *res_d = reinterpret_cast<float *>(lds_raw);
-	int *res_i = reinterpret_cast<int *>(res_d + (ef + 2));
-	float *cand_d = reinterpret_cast<float *>(res_i + (ef + 2));
-	int *cand_i = reinterpret_cast<int *>(cand_d + (cand_cap + 2));
-	int *ids_s = cand_i + (cand_cap + 2);
-	float *dist_s = reinterpret_cast<float *>(ids_s + 64);
+	uint2 *res_h = reinterpret_cast<uint2 *>(lds_raw);
+	uint2 *cand_h = res_h + ((ef + 3) & ~1);
+	int *ids_s = reinterpret_cast<int *>(cand_h + ((cand_cap + 3) & ~1));
+	unsigned *dist_s = reinterpret_cast<unsigned *>(ids_s + 64);
 	int *code_s = reinterpret_cast<int *>(dist_s + 64);
-	const LdsHeap<true> cand{cand_d, cand_i};
-	const LdsHeap<false> res{res_d, res_i};
+	const LdsHeap<true> cand{cand_h, (unsigned)(size_t)cand_h};
+	const LdsHeap<false> res{res_h, (unsigned)(size_t)res_h};
 
 	QueryRegs<J> Q;
 	load_query<J>(Q, a.q + (size_t)qi * (size_t)ix.dim, ix.dim, lane);
 
 	int n_dist = 0, n_l0 = 0, n_up = 0, found = 0;
+#ifdef MVDB_TRAVERSE_PROFILE
+	unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
 
 	// search(): hnsw.ts:961-967 (entry validity is established by the host before launch)
 	int cur = ix.entry, cur_code = ix.entry_code;
-	float cur_d;
+	unsigned cur_d;  // f32 bit pattern, see LdsHeap
 	{
 		if (lane == 0) ids_s[0] = cur;
 		dist_rows<J, FULL>(ix, Q, ids_s, dist_s, 1, cur, lane);
-		cur_d = rfl(dist_s[0]);  // :969
+		cur_d = (unsigned)rfl((int)dist_s[0]);  // :969
 		n_dist++;
 	}
 
@@ -275,18 +362,18 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 				dist_rows<J, FULL>(ix, Q, ids_s, dist_s, n, cur, lane);
 				n_dist += n;
 				// sequential scan with strict `<` == first occurrence of the minimum, if below cur_d
-				float d = lane < n ? dist_s[lane] : __builtin_inff();
+				unsigned d = lane < n ? dist_s[lane] : 0xffffffffu;
 				int idx = lane;
 #pragma unroll
 				for (int off = 32; off >= 1; off >>= 1) {
-					const float od = __shfl_xor(d, off);
+					const unsigned od = (unsigned)__shfl_xor((int)d, off);
 					const int oi = __shfl_xor(idx, off);
 					if (od < d || (od == d && oi < idx)) {
 						d = od;
 						idx = oi;
 					}
 				}
-				d = rfl(d);
+				d = (unsigned)rfl((int)d);
 				idx = rfl(idx);
 				if (d < cur_d) {  // :997-1001
 					cur_d = d;
@@ -298,81 +385,139 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 		}
 	}
 
+	MVDB_STAMP(0);  // query load + descent
 	// search_layer(query, cur, 0, ef, false): hnsw.ts:423-523
 	uint32_t *vis = a.visited + (size_t)qi * a.vis_words;
 	int cand_size = 0, res_size = 0;
 	{
 		// dist0 (:450) re-evaluates the row the descent ended on: same value, counted, not re-read
-		const float d0 = cur_d;
+		const unsigned d0 = cur_d;
 		n_dist++;
 		if (lane == 0) atomicOr(&vis[(unsigned)cur >> 5], 1u << (cur & 31));  // :452
 		cand.push(cand_size++, cur, d0, lane);                                 // :453
 		res.push(res_size++, cur, d0, lane);                                   // :454
 	}
-	float worst = rfl(res_d[1]);
+	unsigned worst = (unsigned)rfl((int)res_h[1].x);
+	HeapPipe<false> rpipe;  // result max-heap operations in flight
+	HeapPipe<true> cpipe;   // the candidate pop in flight
+	rpipe.base = (unsigned)(size_t)res_h;
+	cpipe.base = (unsigned)(size_t)cand_h;
+	// Spend up to `n` ticks on the candidate pop in flight (called while global loads are
+	// outstanding).  Result-heap operations still in flight ride along with the ticks of the next
+	// admission loop; only the candidate heap must be quiescent before the next push.
+	auto background = [&](int n) {
+		for (int i = 0; i < n; i++) {
+			if (!cpipe.busy()) break;
+			cpipe.tick();
+		}
+	};
 
 	while (cand_size > 0) {  // :459
-		int c_id;
-		float c_d;
-		cand_size = cand.pop(cand_size, c_id, c_d, lane);  // :460
+		// cand_pop (:173-213): the root leaves now, its sift-down runs in the background
+		cpipe.drain();
+		const uint2 croot = cand_h[1];
+		const int c_id = rfl((int)croot.y);
+		const unsigned c_d = (unsigned)rfl((int)croot.x);
+		cand_size--;
+		if (cand_size > 0) {
+			const uint2 last = cand_h[cand_size + 1];
+			cpipe.issue(lane, cand_size, last.x, last.y);
+		}
+		MVDB_STAMP(1);  // candidate pop
 		if (res_size >= ef && c_d > worst) break;          // :466 (strict >)
 		n_l0++;
 		const int32_t *lst = ix.adj0 + (size_t)c_id * (size_t)ix.m0;
 		for (int base = 0; base < ix.m0; base += 64) {
 			int nb = -1;
 			if (base + lane < ix.m0) nb = lst[base + lane];
+			background(6);
 			bool isnew = false;
+			uint32_t old = 0, bit = 0;
 			if (nb >= 0) {  // :494-495 visited test-and-set
-				const uint32_t bit = 1u << (nb & 31);
-				const uint32_t old = atomicOr(&vis[(unsigned)nb >> 5], bit);
-				isnew = !(old & bit);
+				bit = 1u << (nb & 31);
+				old = atomicOr(&vis[(unsigned)nb >> 5], bit);
 			}
+			background(6);
+			isnew = nb >= 0 && !(old & bit);
 			const unsigned long long nm = __ballot(isnew);
 			const int n = __builtin_popcountll(nm);
+			MVDB_STAMP(2);  // neighbour list + visited test-and-set
 			if (__ballot(nb >= 0) == 0) break;
 			if (n == 0) continue;
 			if (isnew) ids_s[__builtin_popcountll(nm & ((1ull << lane) - 1))] = nb;
 			dist_rows<J, FULL>(ix, Q, ids_s, dist_s, n, c_id, lane);  // :497
 			n_dist += n;
-			for (int t = 0; t < n; t++) {
-				const float d = rfl(dist_s[t]);
-				if (res_size < ef || d < worst) {  // :499
-					const int nid = rfl(ids_s[t]);
-					if (cand_size < cand_cap) cand.push(cand_size++, nid, d, lane);  // :500-502
-					if (res_size < ef) res.push(res_size++, nid, d, lane);           // :504-505
-					else res.sift_root(res_size, nid, d, lane);                      // :506-507 (d < worst holds)
-					worst = rfl(res_d[1]);
+			MVDB_STAMP(3);  // row gather + distances
+			cpipe.drain();  // pushes below read ancestor chains of the candidate heap
+			// admission in list order (:499-508).  `worst` only falls while a list is processed, so a
+			// neighbour rejected once stays rejected: jump straight to the next one below `worst`.
+			const unsigned my_d = lane < n ? dist_s[lane] : 0xffffffffu;
+			const int my_id = lane < n ? ids_s[lane] : -1;
+			unsigned long long rem = n >= 64 ? ~0ull : ((1ull << n) - 1);
+			for (;;) {
+				const unsigned long long m = (res_size < ef ? ~0ull : __ballot(my_d < worst)) & rem;
+				if (m == 0) break;
+				const int t = __builtin_ctzll(m);
+				rem &= ~((2ull << t) - 1);
+				const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)my_d, t);
+				const int nid = __builtin_amdgcn_readlane(my_id, t);
+#ifdef MVDB_TRAVERSE_PROFILE
+				prof_acc[7]++;  // admitted neighbours
+#endif
+				if (cand_size < cand_cap) cand.push(cand_size++, nid, d, lane);  // :500-502
+				if (res_size < ef) {
+					// :504-505; nothing is in flight on the result heap before it is full
+					res.push(res_size++, nid, d, lane);
+					worst = (unsigned)rfl((int)res_h[1].x);
+				} else {
+					// :506-507 replace_root, pipelined.  The youngest operation in flight has taken its
+					// root step (level 2 at most); one tick puts it on level 3, which frees the root.
+					rpipe.tick();
+					const int owner = rpipe.issue(lane, res_size, d, (unsigned)nid);
+					rpipe.tick();  // its root step: the root is final again
+					worst = (unsigned)__builtin_amdgcn_readlane((int)rpipe.root_key, owner);
 				}
 			}
+			MVDB_STAMP(4);  // heap updates
 		}
 	}
 
-	// res_to_sorted_full (:317-325): repeated max-heap pops, written back to front.
+	// res_to_sorted_full (:317-325): repeated max-heap pops, written back to front, pipelined.
 	// The candidate heap is dead now; its arrays stage the sorted output.
 	found = res_size;
-	{
-		int n = res_size;
-		for (int i = found - 1; i >= 0; i--) {
-			int rid;
-			float rd;
-			n = res.pop(n, rid, rd, lane);
-			if (lane == 0) {
-				cand_i[i] = rid;
-				cand_d[i] = rd;
-			}
+	rpipe.drain();
+	cpipe.drain();
+	for (int i = 0; i < found; i++) {
+		const int last = found - i;  // slot of the entry this pop carries to the root
+		rpipe.tick();                // the previous pop leaves level 2
+		while (rpipe.on_chain_to(last)) rpipe.tick();
+		const uint2 root = res_h[1];
+		const uint2 e = res_h[last];
+		if (lane == 0) cand_h[found - 1 - i] = root;
+		if (last > 1) {
+			rpipe.issue(lane, last - 1, e.x, e.y);
+			rpipe.tick();
 		}
 	}
+	rpipe.drain();
+	MVDB_STAMP(5);  // final heap sort
 	int out_count = found < a.k ? found : a.k;  // :1015-1017
 	if (out_count > a.results_cap) out_count = a.results_cap;
 	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
 	for (int i = lane; i < out_count; i += 64) {  // :1019-1024
-		a.out_ids[(size_t)qi * (size_t)a.k + i] = cand_i[i];
-		a.out_dist[(size_t)qi * (size_t)a.k + i] = cand_d[i];
+		const uint2 e = cand_h[i];
+		a.out_ids[(size_t)qi * (size_t)a.k + i] = (int)e.y;
+		a.out_dist[(size_t)qi * (size_t)a.k + i] = __uint_as_float(e.x);
 	}
 	for (int i = out_count + lane; i < a.k; i += 64) {  // deterministic tail of a ragged row
 		a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
 		a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
 	}
+#ifdef MVDB_TRAVERSE_PROFILE
+	MVDB_STAMP(6);  // output
+	if (lane == 0 && a.prof)
+		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * 8 + i] = prof_acc[i];
+#endif
 	if (lane == 0) {
 		a.out_count[qi] = out_count;
 		if (a.ctr) {
