@@ -322,10 +322,8 @@ int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 	MVDB_T(4)
 	MVDB_T(6)
 	MVDB_T(8)
-	MVDB_T(12)
-	MVDB_T(16)
 #undef MVDB_T
-	h->set_error("dim > 2048 is not supported by the traversal kernel");
+	h->set_error("dim > 1024 is not supported by the traversal kernel");
 	return 0;
 }
 
