@@ -252,10 +252,13 @@ class MiniVectorDB:
         return self.searchMany([q], opts)[0]
 
     # ---- persistence ---------------------------------------------------------------------------
-    def save(self):                                               # :692, :1589-1632
+    def _save_meta(self):
         with open(self.metaPath + ".tmp", "w") as f:
             json.dump(dict(items={str(k): v for k, v in self._items.items()}, next_id=self._next_id), f)
         os.replace(self.metaPath + ".tmp", self.metaPath)
+
+    def save(self):                                               # :692, :1589-1632
+        self._save_meta()
         self.wasm.save(self.dumpPath + ".tmp")
         os.replace(self.dumpPath + ".tmp", self.dumpPath)
         with open(self.statePath, "w") as f:
@@ -268,6 +271,8 @@ class MiniVectorDB:
         return dict(dim=self.cfg["dim"], mode=self.mode, capacity=self.capacity, items=active,
                     deleted=len(self._items) - active, m=self.cfg["m"], ef_construction=self.cfg["ef_construction"])
 
-    def close(self):                                              # :943-957
+    def close(self):                                              # :943-957 (the metadata store is flushed)
+        if self.isReady:
+            self._save_meta()
         self.wasm.close()
         self.isReady = False
