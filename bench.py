@@ -85,6 +85,7 @@ def main():
     import torch.distributed as dist
 
     from minivectordb_amd import HipBridge, resolve_preset, derive_search_params
+    from minivectordb_amd.distributed import gather_topk
     from minivectordb_amd.pipeline import ResidentSearcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,19 +161,10 @@ def main():
             return ids, l2, n
         if sharded:
             gid = ids + id_offset if id_offset else ids
-            all_ids = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=dev)
-            all_l2 = torch.empty((world,) + tuple(l2.shape), dtype=l2.dtype, device=dev)
-            all_n = torch.empty((world,) + tuple(n.shape), dtype=n.dtype, device=dev)
-            dist.all_gather_into_tensor(all_ids, gid.contiguous())
-            dist.all_gather_into_tensor(all_l2, l2.contiguous())
-            dist.all_gather_into_tensor(all_n, n.contiguous())
+            all_ids, all_l2, all_n = gather_topk(gid, l2, n)          # the one exchange step (RCCL all-gather)
             return searcher.merge_topk(all_ids, all_l2, all_n, world, nq)
         # replicas: every rank ends up with every rank's answers
-        all_ids = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=dev)
-        all_l2 = torch.empty((world,) + tuple(l2.shape), dtype=l2.dtype, device=dev)
-        dist.all_gather_into_tensor(all_ids, ids.contiguous())
-        dist.all_gather_into_tensor(all_l2, l2.contiguous())
-        return all_ids, all_l2, n
+        return gather_topk(ids, l2, n)
 
     # ---------------- warmup + timed region -----------------------------------------------------
     log(f"rank {rank}: warmup {args.warmup} steps (first step uploads the index)")

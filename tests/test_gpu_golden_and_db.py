@@ -158,3 +158,32 @@ def test_properties_at_scale(gpu):
     oi, ol, on, ann, acnt, _ = O.search_many_db(ix, q[sub], base, 10, "balanced", threads=8)
     assert np.array_equal(ann, ids[sub]) and np.array_equal(oi, ti[sub])
     assert np.array_equal(ol.view(np.uint64), tl[sub].view(np.uint64))
+
+
+def test_merge_topk_kernel_matches_host_merge(gpu):
+    """Sharded path: the HIP merge of per-shard top-k lists == the (l2, id) host merge."""
+    import torch
+
+    from minivectordb_amd.distributed import merge_topk_host
+    from minivectordb_amd.pipeline import ResidentSearcher
+    b = HipBridge()
+    b.init(dict(dim=16, m=4, ef=20, capacity=4, seed=1))
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    parts, nq, topk = 8, 300, 10
+    l2 = np.sort(rng.integers(0, 40, (parts, nq, topk)).astype(np.float64) / 8, axis=2)   # many ties across shards
+    ids = rng.permutation(parts * nq * topk).astype(np.int32).reshape(parts, nq, topk)
+    for p in range(parts):                                                               # ids ascending inside ties
+        for q in range(nq):
+            order = np.lexsort((ids[p, q], l2[p, q]))
+            ids[p, q], l2[p, q] = ids[p, q][order], l2[p, q][order]
+    n = rng.integers(0, topk + 1, (parts, nq)).astype(np.int32)
+    s = ResidentSearcher(b, nq, topk, dev)
+    oi, ol, on = s.merge_topk(torch.from_numpy(ids).to(dev), torch.from_numpy(l2).to(dev),
+                              torch.from_numpy(n).to(dev), parts, nq)
+    ei, el, en = merge_topk_host(ids, l2, n, topk)
+    on = on.cpu().numpy()
+    assert np.array_equal(on, en)
+    for q in range(nq):
+        assert np.array_equal(oi.cpu().numpy()[q, :en[q]], ei[q, :en[q]])
+        assert np.array_equal(ol.cpu().numpy()[q, :en[q]], el[q, :en[q]])
