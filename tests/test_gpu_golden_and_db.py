@@ -187,3 +187,15 @@ def test_merge_topk_kernel_matches_host_merge(gpu):
     for q in range(nq):
         assert np.array_equal(oi.cpu().numpy()[q, :en[q]], ei[q, :en[q]])
         assert np.array_equal(ol.cpu().numpy()[q, :en[q]], el[q, :en[q]])
+
+
+def test_node_napi_bridge(gpu):
+    """The N-API addon + node/hip-bridge.js (the WasmBridge drop-in for the Node.js host)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("node") is None or not os.path.exists(os.path.join(root, "node", "mvdb_napi.node")):
+        pytest.skip("node or the built addon is not present on this box")
+    r = subprocess.run(["node", os.path.join(root, "node", "test_bridge.js")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "node bridge test passed" in r.stdout
