@@ -2,6 +2,9 @@
 
 torch is plumbing only here: it owns device memory and the stream; every kernel is
 launched by libmvdb_hip.so through the `_dev` entry points of include/mvdb_hip.h.
+
+Process rule: when torch shares the process, initialise torch's device first
+(``torch.cuda.init()`` / ``torch.cuda.set_device``) and create HipBridge objects afterwards.
 """
 from __future__ import annotations
 

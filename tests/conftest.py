@@ -27,6 +27,14 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def gpu():
+    # torch (used as plumbing by the resident-pipeline tests) must bring its HIP runtime up before
+    # libmvdb_hip.so touches the device; the other order leaves torch with "No HIP GPUs are available".
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from minivectordb_amd import _native
     if not _native.lib().mvdb_device_available():
         pytest.fail("no HIP device visible: GPU tests cannot run (there is no CPU fallback)")
