@@ -204,8 +204,15 @@ def main():
     b_rerank = ctr[:, 3] * dim * 4 + dim * 4 + tk * 8
     trav_ms = trav_ms_total / max(n_launch, 1)
     achieved = float(b_ann.sum()) / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+    # HBM traffic per launch: FETCH_SIZE from a separate rocprofv3 --pmc pass of this workload, corrected
+    # by the gfx950 calibration recorded next to it (profiles/r1/pmc_traffic_1m_balanced.json)
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_1m_balanced.json")
+    if N == 1_000_000 and dim == 384 and nq == 1000 and args.preset == "balanced" and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            traffic = int(json.load(f)["traverse"]["corrected_bytes_per_launch"])
     roofline = dict(bound="hbm", kernel="traverse_kernel", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     algorithmic_bytes_per_launch=int(b_ann.sum()), avg_launch_ms=round(trav_ms, 4),
                     rerank_bytes_per_launch=int(b_rerank.sum()),
                     rerank_avg_launch_ms=round(rerank_ms_total / max(n_launch, 1), 4),
