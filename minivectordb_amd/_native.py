@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvdb_hip.so")
+# MVDB_HIP_LIB selects a tuning variant built by tools/ (same ABI, same kernels, other constants)
+LIB_PATH = os.environ.get("MVDB_HIP_LIB") or os.path.join(_HERE, "lib", "libmvdb_hip.so")
 
 
 class MvdbError(RuntimeError):

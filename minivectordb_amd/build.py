@@ -21,16 +21,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str | None = None) -> str:
+    """Build the library.  `defines`/`out` build a tuning variant (tools/ only) beside it."""
+    target = LIB if out is None else os.path.join(LIB_DIR, out)
+    if out is None and not force and not _stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-fno-fast-math", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
+    cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-o", LIB]
+    cmd += ["-o", target]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -39,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed building libmvdb_hip.so")
     if verbose and r.stderr:
         sys.stderr.write(r.stderr)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

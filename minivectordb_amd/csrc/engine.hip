@@ -456,8 +456,11 @@ int mvdb_prepare_queries_dev(mvdb_index *h, const float *d_q_in, int nq, float *
 	if (nq <= 0) return 1;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	StageTimer t(h, 0, s);
-	hipLaunchKernelGGL(prep_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_q_in, nq, h->cfg.dim, d_q_norm_out,
-	                   d_q_i8_out);
+	if (h->cfg.dim > kPrepMaxDim) {
+		h->set_error("prepare_queries: dim exceeds the staging row (4096)");
+		return 0;
+	}
+	hipLaunchKernelGGL(prep_kernel, dim3(nq), dim3(64), 0, s, d_q_in, nq, h->cfg.dim, d_q_norm_out, d_q_i8_out);
 	HIP_OK(h, hipGetLastError());
 	return 1;
 }
