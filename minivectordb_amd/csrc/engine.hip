@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -17,6 +18,7 @@
 #include "rerank.hip.hpp"
 #include "scan.hip.hpp"
 #include "traverse.hip.hpp"
+#include "traverse_duo.hip.hpp"
 
 using namespace mvdb;
 
@@ -305,16 +307,40 @@ int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStrea
 	return 1;
 }
 
+template <int J, bool FULL>
+int launch_traverse_duo_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
+{
+	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&traverse_duo_kernel<J, FULL>),
+	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((traverse_duo_kernel<J, FULL>), dim3(a.nq), dim3(kDuoThreads), lds, s, a);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+// Two waves per query (traverse_duo.hip.hpp) whenever a neighbour list fits one 64-lane chunk;
+// MVDB_TRAVERSE_WAVES=1 selects the one-wave kernel for A/B timing.
+bool traverse_use_duo(const TraverseArgs &a)
+{
+	const char *e = std::getenv("MVDB_TRAVERSE_WAVES");
+	const int forced = e ? std::atoi(e) : 0;
+	return a.ix.m0 <= kDuoMaxM0 && forced != 1;
+}
+
 int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 {
-	const size_t lds = traverse_lds_bytes(a.ef, a.cand_cap);
+	const bool duo = traverse_use_duo(a);
+	const size_t lds = duo ? traverse_duo_lds_bytes(a.ef, a.cand_cap) : traverse_lds_bytes(a.ef, a.cand_cap);
 	const int stride = a.ix.row_stride;
 	const int J = (stride + 127) / 128;
 	const bool full = stride == J * 128;
-#define MVDB_T(JJ)                                                      \
-	if (J <= JJ) {                                                      \
-		if (full && J == JJ) return launch_traverse_t<JJ, true>(h, a, lds, s); \
-		return launch_traverse_t<JJ, false>(h, a, lds, s);              \
+#define MVDB_T(JJ)                                                                          \
+	if (J <= JJ) {                                                                          \
+		if (duo) {                                                                          \
+			if (full && J == JJ) return launch_traverse_duo_t<JJ, true>(h, a, lds, s);      \
+			return launch_traverse_duo_t<JJ, false>(h, a, lds, s);                          \
+		}                                                                                   \
+		if (full && J == JJ) return launch_traverse_t<JJ, true>(h, a, lds, s);              \
+		return launch_traverse_t<JJ, false>(h, a, lds, s);                                  \
 	}
 	MVDB_T(1)
 	MVDB_T(2)
@@ -537,7 +563,7 @@ int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		a.ctr = d_ctr ? d_ctr + q0 : nullptr;
 		a.prof = nullptr;
 #ifdef MVDB_TRAVERSE_PROFILE
-		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 64)) + (size_t)q0 * 8;
+		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 128)) + (size_t)q0 * 16;
 #endif
 		if (!launch_traverse(h, a, s)) return 0;
 	}
@@ -565,6 +591,11 @@ int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out
 	if (!mvdb_search_many_dev(h, d_q, nq, k, d_ids, d_dist, d_cnt, d_ctr, nullptr)) return 0;
 	HIP_OK(h, hipDeviceSynchronize());
 	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+	for (int i = 0; i < nq; i++)
+		if (out_count[i] < 0) {  // traverse_duo.hip.hpp: a wave gave up waiting, or the pop check failed
+			h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
+			return 0;
+		}
 	if (k > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_ids, nk * 4, hipMemcpyDeviceToHost));
 		HIP_OK(h, hipMemcpy(out_dist, d_dist, nk * 4, hipMemcpyDeviceToHost));
@@ -866,6 +897,11 @@ int mvdb_scan_many(mvdb_index *h, const int8_t *q, int nq, int k, int metric, in
 	if (!mvdb_scan_many_dev(h, d_q, nq, k, metric, d_ids, d_val, d_cnt, nullptr)) return 0;
 	HIP_OK(h, hipDeviceSynchronize());
 	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+	for (int i = 0; i < nq; i++)
+		if (out_count[i] < 0) {  // traverse_duo.hip.hpp: a wave gave up waiting, or the pop check failed
+			h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
+			return 0;
+		}
 	if (k > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
 		HIP_OK(h, hipMemcpy(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
@@ -894,7 +930,7 @@ int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2,
 int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 {
 	if (!h->prof_buf.p) return 0;
-	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 64, hipMemcpyDeviceToHost) == hipSuccess;
+	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 128, hipMemcpyDeviceToHost) == hipSuccess;
 }
 #endif
 void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }

@@ -135,7 +135,8 @@ struct HeapPipe {
 	unsigned a = 0;     // this lane's operation: 8 * position, 0 = idle
 	unsigned lim = 0;   // 8 * heap size the operation works in
 	unsigned key = 0, id = 0;
-	unsigned root_key = 0;  // in the lane whose operation just took its root step: the new root key
+	unsigned root_key = 0;  // in the lane whose operation just took its root step: the new root entry
+	unsigned root_id = 0;
 	int next_lane = 0;
 
 	__device__ __forceinline__ bool busy() const { return __ballot(a != 0) != 0; }
@@ -175,6 +176,7 @@ struct HeapPipe {
 		const u32x2_t w = {stop ? key : kc, stop ? id : ic};
 		*reinterpret_cast<lds_u32x2 *>((size_t)(base + a)) = w;
 		root_key = a == 8 ? w.x : root_key;
+		root_id = a == 8 ? w.y : root_id;
 		a = stop ? 0u : ca + (right ? 8u : 0u);
 	}
 	__device__ __forceinline__ void drain()
@@ -281,7 +283,7 @@ struct TraverseArgs {
 	float *out_dist;      // nq x k
 	int32_t *out_count;   // nq
 	mvdb_query_counters *ctr;  // nq or null
-	unsigned long long *prof;  // diagnostic builds only (MVDB_TRAVERSE_PROFILE): nq x 8 cycle sums
+	unsigned long long *prof;  // diagnostic builds only (MVDB_TRAVERSE_PROFILE): nq x 16 cycle sums
 };
 
 #ifdef MVDB_TRAVERSE_PROFILE
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 #ifdef MVDB_TRAVERSE_PROFILE
 	MVDB_STAMP(6);  // output
 	if (lane == 0 && a.prof)
-		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * 8 + i] = prof_acc[i];
+		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * 16 + i] = prof_acc[i];
 #endif
 	if (lane == 0) {
 		a.out_count[qi] = out_count;

@@ -1,0 +1,606 @@
+// traverse_duo.hip.hpp -- the layer-0 search of traverse.hip.hpp split over TWO waves per query.
+//
+// Same algorithm, same bit-exact heaps (hnsw.ts:423-523, :141-325); what changes is who runs what:
+//   access wave (wave 0): owns the candidate min-heap and everything that touches HBM -- pops,
+//       neighbour list, visited test-and-set, int8 rows, distances -- and replays the pushes
+//       the result wave hands it;
+//   result wave (wave 1): owns the result max-heap -- admission in list order (:499-508),
+//       replace_root sift-downs (pipelined, HeapPipe), the final heap sort.
+// One wave per SIMD issues at most one instruction every four cycles, and a query is a serial
+// chain; two waves give the chain two issue ports and let the memory phase of expansion t+1 run
+// under the admission of expansion t.  That needs the identity of the NEXT candidate before the
+// current list has been admitted, and it is known exactly, without speculation:
+//   * distances of the whole list are computed before admission starts;
+//   * `worst` only falls while a list is processed, so if the FIRST-occurrence minimum d_min of
+//     the list is below `worst` at the start it is admitted (fewer than ef entries are <= d_min
+//     then, and everything admitted before it is strictly larger);
+//   * every push of this list has key >= d_min, and a sift-up passes a parent only when strictly
+//     smaller (:163), so after the pushes the candidate root is the d_min neighbour when
+//     d_min < key(r), else r, the root the pop's sift-down leaves (final after its first step).
+// Cases where this does not hold by construction (result heap filling up inside the list,
+// candidate heap about to overflow and drop pushes, :500) take the unpredicted path: the access
+// wave waits for the admission, replays the pushes and reads the root.  Every pop re-checks
+// that the root IS the candidate whose list was fetched; a mismatch aborts the query (count -1).
+//
+// The waves talk through LDS only, no barriers: single-writer 16-byte mailboxes, each written
+// by lane 0 with one ds_write_b128 and read with one ds_read_b128 (LDS executes whole
+// instructions in order, so a snapshot is never torn):
+//   record[e & 1] (access -> result): {records published, kind | n | buffer, id, key}
+//   channel       (result -> access): {admitted-lane mask (8 B), 2*record + done, worst}
+//   sift_done     (access -> result): last pop whose sift-down has left the candidate heap
+// Timeline of expansion e:  the access wave publishes record e as soon as the distances are
+// there (the result wave may still be busy with e-1); the result wave admits the list into the
+// result heap, then -- once sift_done >= e -- replays the admitted neighbours into the
+// candidate heap (:500-502; the two heaps are independent, so doing the pushes after the
+// admissions leaves the same arrays) and posts the channel; the access wave then pops e+1 and
+// starts its memory phase while the result wave is already admitting list e+1... Both waves
+// evaluate the termination test (:466) from the same values.  Every wait is bounded; a wave that
+// gives up raises `abort` and the query reports count -1.
+// Memory phase: the visited test-and-set and the row gather of ALL listed neighbours are issued
+// together (about nine in ten listed neighbours are new at ef ~ 1200, the rest is discarded),
+// the list of the root the pop leaves is fetched at pop time, and one dword of every listed
+// neighbour's own list is touched so that the next list is an L2 hit.
+#pragma once
+
+#include "traverse.hip.hpp"
+
+namespace mvdb {
+
+#ifndef MVDB_DUO_POSTPOP_TICKS
+#define MVDB_DUO_POSTPOP_TICKS 0  // measured at 1M x 384, ef 1200: 0 -> 3.87 ms, 4 -> 3.98, 16 -> 4.16
+#endif
+constexpr int kDuoThreads = 128;
+constexpr int kDuoMaxM0 = 64;       // one 64-lane chunk per neighbour list
+constexpr int kDuoSpinLimit = 1 << 20;
+
+enum : int { kRecInit = 0, kRecList = 1, kRecEnd = 2 };
+
+struct DuoSync {
+	u32x4_t record[2];  // access wave -> result wave, by record parity
+	u32x4_t channel;    // result wave -> access wave
+	int sift_done;      // access wave -> result wave
+	int fin;            // access wave: counters below are final
+	int abort;
+	int n_dist, n_l0, n_up;  // handed over with the END record
+	int sink;                // keeps the L2-warming loads alive, never read
+};
+
+// minimum over the wave, in every lane's scalar view (DPP within rows of 16, then 4 readlanes)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
+{
+	auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+	const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0), b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
+	const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32), d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+	return mn(mn(a, b), mn(c, d));
+}
+
+__device__ __forceinline__ u32x4_t duo_snapshot(const u32x4_t *p)
+{
+	const u32x4_t v = *reinterpret_cast<const volatile lds_u32x4 *>((size_t)(unsigned)(size_t)p);
+	return u32x4_t{(unsigned)rfl((int)v.x), (unsigned)rfl((int)v.y), (unsigned)rfl((int)v.z), (unsigned)rfl((int)v.w)};
+}
+// publish: everything this wave wrote to LDS before is visible to whoever sees the new mailbox
+__device__ __forceinline__ void duo_publish(u32x4_t *p, u32x4_t v, int lane)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	if (lane == 0) *reinterpret_cast<volatile lds_u32x4 *>((size_t)(unsigned)(size_t)p) = v;
+}
+
+// LDS carve: res[ef+2] cand[cap+2] | ids[2][64] dist[2][64] all_ids[64] all_dist[64] code[64] | DuoSync
+__host__ __device__ inline size_t traverse_duo_lds_bytes(int ef, int cand_cap)
+{
+	return (size_t)8 * (size_t)((ef + 3) & ~1) + (size_t)8 * (size_t)((cand_cap + 3) & ~1) + (size_t)4 * 7 * 64 +
+	       sizeof(DuoSync);
+}
+
+// diagnostic cycle stamps (MVDB_TRAVERSE_PROFILE builds only); slots, access wave: 0 descent,
+// 1 early memory phase, 2 wait for admission + replay, 3 late (unpredicted) memory phase,
+// 4 pop + publish + prediction, 8 unpredicted expansions; result wave: 5 wait for a record,
+// 6 admission, 7 final sort, 9 admitted neighbours
+#ifdef MVDB_TRAVERSE_PROFILE
+#define MVDB_DUO_STAMP(slot)                                          \
+	do {                                                              \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+		prof_acc[slot] += now_ - prof_last;                           \
+		prof_last = now_;                                             \
+	} while (0)
+#else
+#define MVDB_DUO_STAMP(slot) \
+	do {                     \
+	} while (0)
+#endif
+
+template <int J, bool FULL>
+__global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs a)
+{
+#ifdef MVDB_TRAVERSE_PROFILE
+	unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+	unsigned long long prof_unsure = 0, prof_admitted = 0;
+#endif
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const int lane = threadIdx.x & 63;
+	const int wave = rfl((int)(threadIdx.x >> 6));
+	const int qi = blockIdx.x;
+	if (qi >= a.nq) return;
+	const DevIndexView &ix = a.ix;
+
+	const int ef = a.ef, cand_cap = a.cand_cap;
+	uint2 *res_h = reinterpret_cast<uint2 *>(lds_raw);
+	uint2 *cand_h = res_h + ((ef + 3) & ~1);
+	int *ids_b = reinterpret_cast<int *>(cand_h + ((cand_cap + 3) & ~1));  // [2][64]
+	unsigned *dist_b = reinterpret_cast<unsigned *>(ids_b + 128);          // [2][64]
+	int *all_ids = reinterpret_cast<int *>(dist_b + 128);
+	unsigned *all_dist = reinterpret_cast<unsigned *>(all_ids + 64);
+	int *code_s = reinterpret_cast<int *>(all_dist + 64);
+	DuoSync *sy = reinterpret_cast<DuoSync *>(code_s + 64);
+	const LdsHeap<true> cand{cand_h, (unsigned)(size_t)cand_h};
+	const LdsHeap<false> res{res_h, (unsigned)(size_t)res_h};
+
+	// each wave clears the mailbox it WRITES; nobody reads before the barrier
+	if (wave == 0) {
+		if (lane == 0) {
+			sy->record[0] = u32x4_t{0, 0, 0, 0};
+			sy->record[1] = u32x4_t{0, 0, 0, 0};
+			sy->sift_done = 0;
+			sy->fin = 0;
+			sy->abort = 0;
+		}
+	} else {
+		if (lane == 0) sy->channel = u32x4_t{0, 0, 0, 0};
+	}
+	__syncthreads();  // the only barrier: both waves reach it unconditionally
+
+	if (wave == 0) {
+		// =========================== access wave ===========================
+		QueryRegs<J> Q;
+		load_query<J>(Q, a.q + (size_t)qi * (size_t)ix.dim, ix.dim, lane);
+		int n_dist = 0, n_l0 = 0, n_up = 0;
+
+		// search(): hnsw.ts:961-969
+		int cur = ix.entry, cur_code = ix.entry_code;
+		unsigned cur_d;
+		{
+			if (lane == 0) all_ids[0] = cur;
+			dist_rows<J, FULL>(ix, Q, all_ids, all_dist, 1, cur, lane);
+			cur_d = (unsigned)rfl((int)all_dist[0]);
+			n_dist++;
+		}
+		// upper-layer greedy descent, :971-1004 (as in traverse_kernel)
+		for (int l = ix.max_level; l > 0; l--) {
+			bool changed = true;
+			while (changed) {
+				changed = false;
+				n_up++;
+				const int lvl = cur_code & 3, cum = cur_code >> 2;
+				if (lvl < l) continue;
+				const int2 *lst = ix.upper + (size_t)(cum + l - 1) * (size_t)ix.m;
+				for (int base = 0; base < ix.m; base += 64) {
+					int2 en = make_int2(-1, -1);
+					if (base + lane < ix.m) en = lst[base + lane];
+					const unsigned long long vm = __ballot(en.x >= 0);
+					const int n = __builtin_popcountll(vm);
+					if (n == 0) break;
+					if (en.x >= 0) {
+						all_ids[lane] = en.x;
+						code_s[lane] = en.y;
+					}
+					dist_rows<J, FULL>(ix, Q, all_ids, all_dist, n, cur, lane);
+					n_dist += n;
+					// sequential scan with strict `<` == first occurrence of the minimum, if below cur_d
+					const unsigned my = lane < n ? all_dist[lane] : 0xffffffffu;
+					const unsigned d = wave_min_u32(my);
+					if (d < cur_d) {  // :997-1001
+						const int idx = __builtin_ctzll(__ballot(my == d));
+						cur_d = d;
+						cur = rfl(all_ids[idx]);
+						cur_code = rfl(code_s[idx]);
+						changed = true;
+					}
+				}
+			}
+		}
+
+		MVDB_DUO_STAMP(0);
+		// search_layer(query, cur, 0, ef, false): :450-454
+		uint32_t *vis = a.visited + (size_t)qi * a.vis_words;
+		int cand_size = 0;
+		n_dist++;  // dist0 (:450) re-evaluates the row the descent ended on
+		if (lane == 0) atomicOr(&vis[(unsigned)cur >> 5], 1u << (cur & 31));
+		cand.push(cand_size++, cur, cur_d, lane);
+		duo_publish(&sy->record[0], u32x4_t{1u, (unsigned)kRecInit, (unsigned)cur, cur_d}, lane);
+
+		HeapPipe<true> cpipe;
+		cpipe.base = (unsigned)(size_t)cand_h;
+		bool dead = false;
+		int res_size = 0;  // tracked from the admitted masks
+		unsigned worst = 0;
+		int sift_e = 0;        // last pop issued
+		bool sift_pub = true;  // sift_done == sift_e has been posted
+		auto post_sift = [&]() {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) *reinterpret_cast<volatile int *>(&sy->sift_done) = sift_e;
+			sift_pub = true;
+		};
+		// work that fits under outstanding global loads: the pop's sift-down
+		auto background = [&](int iters) {
+			for (int i = 0; i < iters; i++) {
+				if (cpipe.busy()) {
+					cpipe.tick();
+					continue;
+				}
+				if (!sift_pub) post_sift();
+				break;
+			}
+		};
+
+		int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
+		int sink = 0;                    // keeps the L2-warming loads alive
+		// neighbour list -> {visited test-and-set, rows of every listed neighbour} -> new ones into buffer b
+		auto mem_phase = [&](int c_id, int b) -> int {
+			int nb = -1;
+			if (pref_id == c_id) nb = pref_nb;
+			else {
+				if (lane < ix.m0) nb = ix.adj0[(size_t)c_id * (size_t)ix.m0 + lane];
+				background(6);
+			}
+			const int cnt = __builtin_popcountll(__ballot(nb >= 0));  // canonical lists: valid prefix
+			MVDB_DUO_STAMP(10);
+			if (cnt == 0) return 0;
+			uint32_t old = 0, bit = 0;
+			if (nb >= 0) {  // :494-495
+				bit = 1u << (nb & 31);
+				old = atomicOr(&vis[(unsigned)nb >> 5], bit);
+				all_ids[lane] = nb;
+			}
+			const int g = lane >> 3, sl = lane & 7;
+			int warm = 0;
+			// 32 rows per pass, all in flight at once; no loop around the passes (a loop makes the
+			// compiler drain vmcnt before every reuse of the row registers)
+			auto pass = [&](const int p0, const bool first) {
+				int4 v[4][J];
+				int slot[4];
+#pragma unroll
+				for (int pp = 0; pp < 4; pp++) {
+					slot[pp] = p0 + pp * 8 + g;
+					const int rid = slot[pp] < cnt ? all_ids[slot[pp]] : c_id;
+					if (p0 + pp * 8 < cnt) load_row<J, FULL>(v[pp], ix, rid, sl);
+				}
+				if (first) {
+					// first dword of every listed neighbour's own list: the next pop's list becomes an L2 hit
+					if (nb >= 0) warm = ix.adj0[(size_t)nb * (size_t)ix.m0];
+					MVDB_DUO_STAMP(11);
+					background(12);
+					MVDB_DUO_STAMP(12);
+				}
+#pragma unroll
+				for (int pp = 0; pp < 4; pp++) {
+					if (p0 + pp * 8 < cnt) {
+						const int tot = Q.qq + reduce8(row_partial<J>(Q, v[pp]));
+						if (sl == 0 && slot[pp] < cnt) all_dist[slot[pp]] = __float_as_uint((float)tot);
+					}
+				}
+			};
+			pass(0, true);
+			if (cnt > 32) pass(32, false);
+			MVDB_DUO_STAMP(13);
+			sink ^= warm;
+			const bool isnew = nb >= 0 && !(old & bit);
+			const unsigned long long nm = __ballot(isnew);
+			const int n = __builtin_popcountll(nm);
+			if (isnew) {
+				const int pos = __builtin_popcountll(nm & ((1ull << lane) - 1));
+				ids_b[64 * b + pos] = nb;
+				dist_b[64 * b + pos] = all_dist[lane];  // :497
+			}
+			MVDB_DUO_STAMP(14);
+			return n;
+		};
+
+		int e = 1;  // record to publish next (expansion e-1)
+		int c_id = cur;
+		unsigned c_d = cur_d;
+		bool have_c = true, published = false;
+		for (;;) {
+			int n = 0;
+			published = false;
+			MVDB_DUO_STAMP(4);
+			if (have_c) {
+				n = mem_phase(c_id, e & 1);
+				duo_publish(&sy->record[e & 1],
+				            u32x4_t{(unsigned)(e + 1), (unsigned)kRecList | ((unsigned)n << 8) | ((unsigned)(e & 1) << 16),
+				                    (unsigned)c_id, c_d},
+				            lane);
+				published = true;
+			}
+			MVDB_DUO_STAMP(1);
+			// the result wave pushes only after this pop's sift-down has left the heap
+			cpipe.drain();
+			if (!sift_pub) post_sift();
+			// ---- record e-1 must be admitted and pushed before the pop
+			u32x4_t ch;
+			for (int spin = 0;;) {
+				ch = duo_snapshot(&sy->channel);
+				if ((int)ch.z == 2 * (e - 1) + 1) break;
+				if (++spin > kDuoSpinLimit || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+					dead = true;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			MVDB_DUO_STAMP(2);
+			if (dead) break;
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			worst = ch.w;
+			{
+				const int adm = __builtin_popcountll((unsigned long long)ch.x | ((unsigned long long)ch.y << 32));
+				if (e == 1) res_size = 1;
+				else {
+					res_size = res_size + adm < ef ? res_size + adm : ef;
+					cand_size = cand_size + adm < cand_cap ? cand_size + adm : cand_cap;  // :500 drops the rest
+				}
+			}
+			if (cand_size == 0) {  // :459
+				if (have_c) dead = true;  // a predicted candidate implies a non-empty heap
+				break;
+			}
+			const uint2 root = cand_h[1];
+			const int r_id = rfl((int)root.y);
+			const unsigned r_key = (unsigned)rfl((int)root.x);
+			if (!have_c) {
+				c_id = r_id;
+				c_d = r_key;
+				n = mem_phase(c_id, e & 1);
+				duo_publish(&sy->record[e & 1],
+				            u32x4_t{(unsigned)(e + 1), (unsigned)kRecList | ((unsigned)n << 8) | ((unsigned)(e & 1) << 16),
+				                    (unsigned)c_id, c_d},
+				            lane);
+				published = true;
+				MVDB_DUO_STAMP(3);
+			} else if (r_id != c_id || r_key != c_d) {
+				dead = true;  // the exactness argument in the header failed: never observed
+				break;
+			}
+			if (res_size >= ef && c_d > worst) break;  // :466 (strict >); the result wave stops on the same test
+			// cand_pop (:173-213): its sift-down runs in the background of the next memory phase
+			cand_size--;
+			int o_id = -1;
+			unsigned o_key = 0;
+			if (cand_size > 0) {
+				const uint2 last = cand_h[cand_size + 1];
+				const int owner = cpipe.issue(lane, cand_size, last.x, last.y);
+				cpipe.tick();  // root step: the root is final
+				o_key = (unsigned)__builtin_amdgcn_readlane((int)cpipe.root_key, owner);
+				o_id = __builtin_amdgcn_readlane((int)cpipe.root_id, owner);
+				pref_id = o_id;  // its list is needed next unless a new neighbour undercuts it
+				pref_nb = -1;
+				if (lane < ix.m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)ix.m0 + lane];
+			}
+			sift_e = e;
+			sift_pub = false;
+			background(MVDB_DUO_POSTPOP_TICKS);  // part of the sift-down under the latency of the list fetch
+			n_l0++;
+			n_dist += n;
+			// ---- who is popped next (see header)
+			have_c = false;
+			const bool full = res_size >= ef;
+			const int free_slots = cand_cap - cand_size;  // pushes beyond these are dropped (:500)
+			if (full || res_size + n <= ef) {
+				const unsigned my_d = lane < n ? dist_b[64 * (e & 1) + lane] : 0xffffffffu;
+				// neighbours that can be admitted at all: below `worst` as it is now (it only falls)
+				const unsigned long long elig = __ballot(lane < n && (!full || my_d < worst));
+				const unsigned d = wave_min_u32(my_d);  // d_min
+				if (elig == 0 || free_slots <= 0) {
+					// nothing is pushed: the root the pop leaves is next (an empty heap ends the search)
+					if (cand_size > 0) {
+						c_id = o_id;
+						c_d = o_key;
+						have_c = true;
+					}
+				} else if (cand_size > 0 && o_key <= d) {
+					c_id = o_id;  // no push can pass the root (:163)
+					c_d = o_key;
+					have_c = true;
+				} else {
+					const int idx = __builtin_ctzll(__ballot(my_d == d));  // first occurrence
+					if (__builtin_popcountll(elig & ((1ull << idx) - 1)) < free_slots) {
+						c_id = rfl(ids_b[64 * (e & 1) + idx]);  // d_min is admitted and still finds a slot
+						c_d = d;
+						have_c = true;
+					} else if (free_slots == 1) {
+						// exactly one push: the first eligible neighbour (admitted: `worst` has not moved yet)
+						const int f = __builtin_ctzll(elig);
+						const unsigned fd = (unsigned)rfl((int)dist_b[64 * (e & 1) + f]);
+						if (cand_size == 0 || fd < o_key) {
+							c_id = rfl(ids_b[64 * (e & 1) + f]);
+							c_d = fd;
+						} else {
+							c_id = o_id;
+							c_d = o_key;
+						}
+						have_c = true;
+					}
+				}
+			}
+#ifdef MVDB_TRAVERSE_PROFILE
+			if (!have_c) prof_unsure++;
+#endif
+			e++;
+		}
+#ifdef MVDB_TRAVERSE_PROFILE
+		MVDB_DUO_STAMP(4);
+		if (lane == 0 && a.prof) {
+			for (int i = 0; i < 5; i++) a.prof[(size_t)qi * 16 + i] = prof_acc[i];
+			for (int i = 10; i < 15; i++) a.prof[(size_t)qi * 16 + i] = prof_acc[i];
+			a.prof[(size_t)qi * 16 + 8] = prof_unsure;
+		}
+#endif
+		cpipe.drain();
+		if (!sift_pub) post_sift();
+		if (lane == 0) {
+			if (dead) sy->abort = 1;
+			sy->n_dist = n_dist;
+			sy->n_l0 = n_l0;
+			sy->n_up = n_up;
+			sy->sink = sink;
+		}
+		if (!published) duo_publish(&sy->record[e & 1], u32x4_t{(unsigned)(e + 1), (unsigned)kRecEnd, 0u, 0u}, lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (lane == 0) *reinterpret_cast<volatile int *>(&sy->fin) = 1;
+		return;
+	}
+
+	// =========================== result wave ===========================
+	int res_size = 0, cand_size = 1;  // the access wave pushed the entry point (:453)
+	unsigned worst = 0;
+	bool dead = false;
+	HeapPipe<false> rpipe;
+	rpipe.base = (unsigned)(size_t)res_h;
+	for (int e = 0;; e++) {
+		u32x4_t rec;
+		for (int spin = 0;;) {
+			rec = duo_snapshot(&sy->record[e & 1]);
+			if ((int)rec.x >= e + 1) break;
+			if (++spin > kDuoSpinLimit || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+				dead = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+		if (dead) break;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		MVDB_DUO_STAMP(5);
+		const int kind = (int)(rec.y & 0xffu);
+		if (kind == kRecEnd) break;
+		unsigned long long adm_mask = 0;
+		if (kind == kRecInit) {
+			res.push(res_size++, (int)rec.z, rec.w, lane);  // :454
+			worst = (unsigned)rfl((int)res_h[1].x);
+		} else {
+			if (res_size >= ef && rec.w > worst) break;  // :466, same values as on the access wave
+			const int n = (int)((rec.y >> 8) & 0xffu), b = (int)((rec.y >> 16) & 1u);
+			// admission in list order (:499-508); see traverse_kernel for the ballot walk
+			const unsigned my_d = lane < n ? dist_b[64 * b + lane] : 0xffffffffu;
+			const int my_id = lane < n ? ids_b[64 * b + lane] : -1;
+			unsigned long long rem = n >= 64 ? ~0ull : ((1ull << n) - 1);
+			for (;;) {
+				const unsigned long long m = (res_size < ef ? ~0ull : __ballot(my_d < worst)) & rem;
+				if (m == 0) break;
+				const int t = __builtin_ctzll(m);
+				rem &= ~((2ull << t) - 1);
+				const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)my_d, t);
+				const int nid = __builtin_amdgcn_readlane(my_id, t);
+#ifdef MVDB_TRAVERSE_PROFILE
+				prof_admitted++;
+#endif
+				adm_mask |= 1ull << t;
+				if (res_size < ef) {
+					res.push(res_size++, nid, d, lane);  // :504-505
+					worst = (unsigned)rfl((int)res_h[1].x);
+				} else {
+					rpipe.tick();  // :506-507 replace_root, pipelined (see traverse_kernel)
+					const int owner = rpipe.issue(lane, res_size, d, (unsigned)nid);
+					rpipe.tick();
+					worst = (unsigned)__builtin_amdgcn_readlane((int)rpipe.root_key, owner);
+				}
+			}
+			MVDB_DUO_STAMP(6);
+			// :500-502 for the admitted neighbours, in list order, once pop e has left the heap
+			for (int spin = 0;;) {
+				if (rfl(*reinterpret_cast<volatile int *>(&sy->sift_done)) >= e) break;
+				if (++spin > kDuoSpinLimit || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+					dead = true;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			if (dead) break;
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			cand_size--;  // pop e
+			for (unsigned long long pm = adm_mask; pm && cand_size < cand_cap; pm &= pm - 1) {
+				const int t = __builtin_ctzll(pm);
+				cand.push(cand_size++, __builtin_amdgcn_readlane(my_id, t), (unsigned)__builtin_amdgcn_readlane((int)my_d, t),
+				          lane);
+			}
+			MVDB_DUO_STAMP(15);
+		}
+		duo_publish(&sy->channel, u32x4_t{(unsigned)adm_mask, (unsigned)(adm_mask >> 32), (unsigned)(2 * e + 1), worst}, lane);
+	}
+	if (dead || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+		if (lane == 0) {
+			sy->abort = 1;
+			a.out_count[qi] = -1;
+			if (a.ctr) {
+				mvdb_query_counters c;
+				c.n_dist = 0;
+				c.n_l0lists = 0;
+				c.n_upperlists = 0;
+				c.n_found = -1;
+				a.ctr[qi] = c;
+			}
+		}
+		for (int i = lane; i < a.k; i += 64) {
+			a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
+			a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
+		}
+		return;
+	}
+
+	// res_to_sorted_full (:317-325): repeated max-heap pops, written back to front, pipelined.
+	// The candidate heap is dead now (the access wave has left); its arrays stage the output.
+	const int found = res_size;
+	rpipe.drain();
+	for (int i = 0; i < found; i++) {
+		const int last = found - i;
+		rpipe.tick();
+		while (rpipe.on_chain_to(last)) rpipe.tick();
+		const uint2 root = res_h[1];
+		const uint2 en = res_h[last];
+		if (lane == 0) cand_h[found - 1 - i] = root;
+		if (last > 1) {
+			rpipe.issue(lane, last - 1, en.x, en.y);
+			rpipe.tick();
+		}
+	}
+	rpipe.drain();
+#ifdef MVDB_TRAVERSE_PROFILE
+	MVDB_DUO_STAMP(7);
+	if (lane == 0 && a.prof) {
+		for (int i = 5; i < 8; i++) a.prof[(size_t)qi * 16 + i] = prof_acc[i];
+		a.prof[(size_t)qi * 16 + 15] = prof_acc[15];
+		a.prof[(size_t)qi * 16 + 9] = prof_admitted;
+	}
+#endif
+	int out_count = found < a.k ? found : a.k;  // :1015-1017
+	if (out_count > a.results_cap) out_count = a.results_cap;
+	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
+	for (int i = lane; i < out_count; i += 64) {  // :1019-1024
+		const uint2 en = cand_h[i];
+		a.out_ids[(size_t)qi * (size_t)a.k + i] = (int)en.y;
+		a.out_dist[(size_t)qi * (size_t)a.k + i] = __uint_as_float(en.x);
+	}
+	for (int i = out_count + lane; i < a.k; i += 64) {
+		a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
+		a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
+	}
+	for (int spin = 0; rfl(*reinterpret_cast<volatile int *>(&sy->fin)) == 0 && spin < kDuoSpinLimit; spin++)
+		__builtin_amdgcn_s_sleep(1);
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	if (lane == 0) {
+		a.out_count[qi] = out_count;
+		if (a.ctr) {
+			mvdb_query_counters c;
+			c.n_dist = sy->n_dist;
+			c.n_l0lists = sy->n_l0;
+			c.n_upperlists = sy->n_up;
+			c.n_found = out_count;
+			a.ctr[qi] = c;
+		}
+	}
+}
+
+}  // namespace mvdb

@@ -33,15 +33,30 @@ if __name__ == "__main__":
     b.setEfSearch(ef)
     for _ in range(3):
         t0 = time.perf_counter(); ids, dist, cnt, ctr = b.searchManyArrays(qi8, ann_k, with_counters=True); t1 = time.perf_counter()
-    prof = np.zeros((nq, 8), np.uint64)
+    prof = np.zeros((nq, 16), np.uint64)
     L = b._L
     L.mvdb_debug_traverse_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     assert L.mvdb_debug_traverse_profile(b.handle, prof.ctypes.data_as(C.c_void_p), nq)
-    names = ["descent", "cand_pop", "list+visited", "rows+dist", "heap_updates", "final_sort", "output", "-"]
-    print("admitted neighbours per query (mean):", prof[:, 7].mean())
-    prof[:, 7] = 0
-    tot = prof.sum(1).astype(np.float64)
-    print(f"host wall of searchMany (incl. copies): {(t1 - t0) * 1e3:.2f} ms; mean cycles/query {tot.mean():.0f}, max {tot.max():.0f}")
+    print(f"host wall of searchMany (incl. copies): {(t1 - t0) * 1e3:.2f} ms")
     print("counters mean:", ctr.mean(0))
-    for i, nm in enumerate(names[:7]):
-        print(f"  {nm:14s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %")
+    if os.environ.get("MVDB_TRAVERSE_WAVES") == "1":
+        names = ["descent", "cand_pop", "list+visited", "rows+dist", "heap_updates", "final_sort", "output"]
+        print("admitted neighbours per query (mean):", prof[:, 7].mean())
+        tot = prof[:, :7].sum(1).astype(np.float64)
+        print(f"mean cycles/query {tot.mean():.0f}, max {tot.max():.0f}")
+        for i, nm in enumerate(names):
+            print(f"  {nm:14s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %")
+    else:
+        acc = ["descent", "early_mem", "wait_adm+replay", "late_mem", "pop+publish+predict"]
+        resw = ["wait_record", "admission", "final_sort"]
+        print(f"  R cand pushes + wait sift {prof[:, 15].mean():12.0f} cyc")
+        for i, nm in zip(range(10, 15), ["mem:list", "mem:issue", "mem:background", "mem:rows+dist", "mem:compact"]):
+            print(f"  A {nm:20s} {prof[:, i].mean():12.0f} cyc")
+        ta = prof[:, :5].sum(1).astype(np.float64) + prof[:, 10:15].sum(1).astype(np.float64)
+        tr = prof[:, 5:8].sum(1).astype(np.float64) + prof[:, 15].astype(np.float64)
+        print(f"access wave: mean cycles {ta.mean():.0f} max {ta.max():.0f}; result wave: mean {tr.mean():.0f} max {tr.max():.0f}")
+        print(f"expansions {ctr[:, 1].mean():.0f}  unpredicted {prof[:, 8].mean():.1f}  admitted {prof[:, 9].mean():.0f}")
+        for i, nm in enumerate(acc):
+            print(f"  A {nm:20s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / ta.sum():5.1f} %")
+        for i, nm in enumerate(resw):
+            print(f"  R {nm:20s} {prof[:, 5 + i].mean():12.0f} cyc  {100 * prof[:, 5 + i].sum() / tr.sum():5.1f} %")
