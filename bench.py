@@ -207,11 +207,15 @@ def main():
     # HBM traffic per launch: FETCH_SIZE from a separate rocprofv3 --pmc pass of this workload, corrected
     # by the gfx950 calibration recorded next to it (profiles/r1/pmc_traffic_1m_balanced.json)
     traffic = None
+    # two waves per query whenever a neighbour list fits one 64-lane chunk (engine.hip: traverse_use_duo)
+    kernel = "traverse_kernel" if (m0 > 64 or os.environ.get("MVDB_TRAVERSE_WAVES") == "1") else "traverse_duo_kernel"
     pmc_file = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_1m_balanced.json")
     if N == 1_000_000 and dim == 384 and nq == 1000 and args.preset == "balanced" and os.path.exists(pmc_file):
         with open(pmc_file) as f:
-            traffic = int(json.load(f)["traverse"]["corrected_bytes_per_launch"])
-    roofline = dict(bound="hbm", kernel="traverse_kernel", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+            pmc = json.load(f)["traverse"]
+        if pmc.get("kernel", "traverse_kernel") == kernel:
+            traffic = int(pmc["corrected_bytes_per_launch"])
+    roofline = dict(bound="hbm", kernel=kernel, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     algorithmic_bytes_per_launch=int(b_ann.sum()), avg_launch_ms=round(trav_ms, 4),
                     rerank_bytes_per_launch=int(b_rerank.sum()),
