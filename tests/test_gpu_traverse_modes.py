@@ -1,0 +1,91 @@
+"""GPU parity of BOTH traversal kernels (one wave per query, two waves per query) against the oracle
+on shapes chosen to reach the corners of the two-wave protocol: result heap filling up inside a
+list, candidate heap saturated (pushes dropped, hnsw.ts:500), lists of 64 neighbours (two row
+passes), M_MAX0 > 64 (one-wave kernel only), tiny graphs, heavy distance ties."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(n, dim, m, efc, seed, coarse=False):
+    rng = np.random.default_rng(seed)
+    if coarse:  # few distinct coordinate values -> many equal int8 distances
+        b8 = (rng.integers(-1, 2, (n, dim)) * 64).astype(np.int8)
+    else:
+        x = rng.standard_normal((n, dim), dtype=np.float32)
+        b8 = O.quantize_rows_i8(O.normalize_rows_f32(x))
+    ix = O.OracleIndex(dim, m, efc, max(n, 1), seed=seed)
+    if n:
+        ix.insert_many(np.arange(n, dtype=np.int32), b8)
+    return ix, b8
+
+
+def _bridge(ix, dim, m, efc):
+    from minivectordb_amd import HipBridge
+    b = HipBridge()
+    b.init(dict(dim=dim, m=m, ef=efc, capacity=8, seed=1))
+    b.loadBytes(ix.save_bytes())
+    b.setResultsCap(4096)
+    ix.set_results_cap(4096)
+    return b
+
+
+def _same(b, ix, q8, k, ef):
+    b.setEfSearch(ef)
+    ix.set_ef_search(ef)
+    oi, od, oc, octr = ix.search_many(q8, k, threads=8)
+    outs = {}
+    for waves in ("1", "2"):
+        os.environ["MVDB_TRAVERSE_WAVES"] = waves
+        try:
+            ids, dist, cnt, ctr = b.searchManyArrays(q8, k, with_counters=True)
+        finally:
+            os.environ.pop("MVDB_TRAVERSE_WAVES", None)
+        assert np.array_equal(cnt, oc), f"waves={waves} k={k} ef={ef}: counts differ"
+        assert np.array_equal(ids, oi), f"waves={waves} k={k} ef={ef}: ids differ"
+        assert np.array_equal(dist.view(np.uint32), od.view(np.uint32)), f"waves={waves}: dists differ"
+        assert np.array_equal(ctr[:, 0], octr["n_dist"]) and np.array_equal(ctr[:, 1], octr["n_l0lists"])
+        assert np.array_equal(ctr[:, 2], octr["n_upperlists"])
+        outs[waves] = ids
+    return outs
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 70])
+def test_tiny_graphs(gpu, n):
+    ix, b8 = _build(n, 32, 8, 40, 3)
+    b = _bridge(ix, 32, 8, 40)
+    q8 = O.quantize_rows_i8(O.normalize_rows_f32(np.random.default_rng(9).standard_normal((24, 32), dtype=np.float32)))
+    for k, ef in [(1, 1), (3, 2), (10, 7), (100, 16), (5, 300)]:
+        _same(b, ix, q8, k, ef)
+
+
+@pytest.mark.parametrize("m", [4, 16, 32, 40])
+def test_list_widths(gpu, m):
+    # m=32 -> 64-entry lists (two row passes in the two-wave kernel); m=40 -> 80 entries (one-wave kernel)
+    ix, b8 = _build(2500, 64, m, 80, 5)
+    b = _bridge(ix, 64, m, 80)
+    q8 = O.quantize_rows_i8(O.normalize_rows_f32(np.random.default_rng(10).standard_normal((48, 64), dtype=np.float32)))
+    for k, ef in [(10, 50), (300, 300), (1200, 140)]:
+        _same(b, ix, q8, k, ef)
+
+
+def test_saturated_candidate_heap(gpu):
+    # ef = MAX_EF: cand_cap = ef, so pushes are dropped for most of the search (hnsw.ts:443-445, :500)
+    ix, b8 = _build(9000, 32, 16, 60, 6)
+    b = _bridge(ix, 32, 16, 60)
+    q8 = O.quantize_rows_i8(O.normalize_rows_f32(np.random.default_rng(11).standard_normal((32, 32), dtype=np.float32)))
+    _same(b, ix, q8, 4096, 4096)
+    _same(b, ix, q8, 2100, 2100)  # cand_cap = min(2*ef+32, 4096) = 4096 < admitted
+
+
+def test_heavy_ties(gpu):
+    ix, b8 = _build(3000, 16, 16, 60, 7, coarse=True)
+    b = _bridge(ix, 16, 16, 60)
+    q8 = (np.random.default_rng(12).integers(-1, 2, (64, 16)) * 64).astype(np.int8)
+    for k, ef in [(10, 10), (64, 64), (500, 500), (1200, 1200)]:
+        _same(b, ix, q8, k, ef)
