@@ -858,15 +858,23 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.qtiles = (nq + kScanQB - 1) / kScanQB;
 	a.s2 = scan_s2_for(nq);
 	a.nsplit = 8 * a.s2;
-	a.nodes_per_split = (((N + a.nsplit - 1) / a.nsplit) + kScanTN - 1) / kScanTN * kScanTN;
+	a.nodes_per_split = (((N + a.nsplit - 1) / a.nsplit) + kScanStage - 1) / kScanStage * kScanStage;
 	const size_t part_elems = (size_t)nq * a.nsplit * k;
-	unsigned char *part = static_cast<unsigned char *>(h->scan_part.need(part_elems * 8 + (size_t)nq * a.nsplit * 4));
+	const size_t part_bytes = part_elems * 8 + (((size_t)nq * a.nsplit * 4 + 7) & ~(size_t)7);
+	unsigned char *part = static_cast<unsigned char *>(h->scan_part.need(part_bytes + (size_t)nq * 8));
 	if (!part) {
 		h->set_error("out of device memory (scan scratch)");
 		return 0;
 	}
 	a.part_key = reinterpret_cast<unsigned long long *>(part);
 	a.part_n = reinterpret_cast<int32_t *>(part + part_elems * 8);
+	a.thr_g = reinterpret_cast<unsigned long long *>(part + part_bytes);
+	HIP_OK(h, hipMemsetAsync(a.thr_g, 0xff, (size_t)nq * 8, s));
+	a.dbg = nullptr;
+#ifdef MVDB_SCAN_DEBUG
+	a.dbg = static_cast<unsigned long long *>(h->prof_buf.need(64));
+	HIP_OK(h, hipMemsetAsync(a.dbg, 0, 64, s));
+#endif
 	a.out_ids = d_out_ids;
 	a.out_val = d_out_val;
 	a.out_count = d_out_count;
@@ -925,8 +933,16 @@ int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2,
 	return 1;
 }
 
+#ifdef MVDB_SCAN_DEBUG
+// diagnostic build only: counters of the last scan launch (tools/scan_debug.py)
+int mvdb_debug_scan_counters(mvdb_index *h, unsigned long long *out)
+{
+	if (!h->prof_buf.p) return 0;
+	return hipMemcpy(out, h->prof_buf.p, 64, hipMemcpyDeviceToHost) == hipSuccess;
+}
+#endif
 #ifdef MVDB_TRAVERSE_PROFILE
-// diagnostic build only: per-query cycle sums of the last traversal launch (nq x 8)
+// diagnostic build only: per-query cycle sums of the last traversal launch (nq x 16)
 int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 {
 	if (!h->prof_buf.p) return 0;

@@ -11,10 +11,13 @@
 // Grid = query tiles x node splits; splits that share `blockIdx % 8` (one XCD, observed
 // round-robin placement: speed only) sweep the SAME node range, so a node tile is fetched from
 // HBM once per XCD and served to the other query tiles from that XCD's L2.
-// Selection: an element is a candidate when its 64-bit key (biased value << 32 | id) is below
-// the row's current k-th key; candidates are appended to a small per-row LDS buffer and merged
-// by one lane per row (64 rows in parallel).  A full buffer never drops anything: the lane keeps
-// the element pending, the wave flushes, and the lane retries.
+// Selection: every query row owns an unsorted LDS buffer of kScanCap 64-bit keys (biased value
+// << 32 | id).  An element that passes the row's 32-bit bound (see "Fast rejection") is appended
+// with one LDS atomic; when a buffer is full the wave compacts that row -- 40 lanes rank the
+// keys against each other through readlane, the best k stay, the k-th becomes the row's new
+// bound -- so the expensive step is paid once per ~kScanCap-k candidates, not per candidate.
+// Nothing is ever dropped: an append that finds the buffer full stays pending until the
+// compaction has run.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,9 +28,10 @@ namespace mvdb {
 
 constexpr int kScanMaxK = 32;
 constexpr int kScanQB = 256;  // queries per workgroup
-constexpr int kScanTN = 32;   // node rows per tile
-constexpr int kScanBuf = 8;   // pending candidates per row
-constexpr int kScanListStride = kScanMaxK + 1;  // u64 entries per row (+1: bank spread)
+constexpr int kScanTN = 32;   // node rows per MFMA pass (two 16-column tiles)
+constexpr int kScanStage = 64;  // node rows staged per barrier (two passes)
+constexpr int kScanCap = 40;  // candidate keys buffered per row before the row is compacted to its best k
+constexpr int kScanListStride = kScanCap + 1;  // u64 entries per row (+1: bank spread)
 
 using v4i = __attribute__((ext_vector_type(4))) int;
 
@@ -37,7 +41,9 @@ struct ScanArgs {
 	const int8_t *q;
 	int nq, k, metric;
 	int qtiles, s2, nsplit;  // nsplit = 8 * s2
-	int nodes_per_split;     // multiple of kScanTN
+	int nodes_per_split;     // multiple of kScanStage
+	unsigned long long *thr_g;     // [nq] smallest k-th key published by any split, ~0 before the launch
+	unsigned long long *dbg;       // MVDB_SCAN_DEBUG builds: 8 counters (see tools/scan_debug.py)
 	unsigned long long *part_key;  // [nq][nsplit][k]
 	int32_t *part_n;               // [nq][nsplit]
 	int32_t *out_ids, *out_val, *out_count;
@@ -53,15 +59,29 @@ __host__ __device__ inline int scan_s2_for(int nq)
 template <int KS>
 __host__ __device__ constexpr size_t scan_lds_bytes()
 {
-	return (size_t)2 * kScanTN * (KS * 64 + 16)                    // node tiles
-	       + (size_t)2 * kScanTN * 4                                // norms of the tiles
-	       + (size_t)4 * (64 * kScanListStride * 8 + 64 * kScanBuf * 8 + 64 * 8 + 64 * 4 + 64 * 4);
+	return (size_t)2 * kScanStage * (KS * 64 + 16)                 // node tiles
+	       + (size_t)2 * kScanStage * 4                             // norms of the tiles
+	       + (size_t)4 * (64 * kScanListStride * 8 + 64 * 8 + 64 * 4 + 64 * 4);
 }
 
 __device__ __forceinline__ unsigned long long scan_key(int val, int id)
 {
 	return ((unsigned long long)((unsigned)val ^ 0x80000000u) << 32) | (unsigned)id;
 }
+
+// Fast rejection.  A candidate needs key < (row's current bound); its necessary condition on the
+// 32-bit value, val <= tv (tv = value part of the bound), is turned into ONE signed compare per
+// accumulator element by folding the column's norm into the MFMA's C operand:
+//   L2:  val = qq + vn - 2c <= tv  <=>  2c - vn >= qq - tv =: u.  With acc = c - (vn >> 1):
+//        2 acc >= 2c - vn, so every candidate has acc >= (u + 1) >> 1 =: g (conservative by the
+//        parity bit of vn at most; the slow path re-checks the exact 64-bit key).
+//   dot: val = -c <= tv  <=>  acc = c >= -tv =: g.
+// Absent rows start from -2^30 and never pass.  While a row has no bound, g = INT_MIN.
+// The bound of a row is the smaller of its own k-th key and the smallest k-th key any other
+// node split has published for the same query (a.thr_g, 64-bit atomicMin, polled every
+// kScanPoll tiles): k keys <= that bound exist, so nothing above it can be in the final top-k.
+// The exchange only prunes; the merged result is the same whatever the timing.
+constexpr int kScanPoll = 4;  // staged tiles between polls of the shared bounds
 
 template <int KS>
 __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
@@ -78,15 +98,14 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 	const int n_begin = split * a.nodes_per_split;
 	int n_end = n_begin + a.nodes_per_split;
 	if (n_end > ix.max_elements) n_end = ix.max_elements;
-	const int ntiles = n_end > n_begin ? (n_end - n_begin + kScanTN - 1) / kScanTN : 0;
+	const int ntiles = n_end > n_begin ? (n_end - n_begin + kScanStage - 1) / kScanStage : 0;  // staged tiles
 
 	unsigned char *btile = lds;
-	int *bnorm = reinterpret_cast<int *>(lds + (size_t)2 * kScanTN * ROWB);
-	unsigned char *wbase = reinterpret_cast<unsigned char *>(bnorm + 2 * kScanTN) +
-	                       (size_t)wave * (64 * kScanListStride * 8 + 64 * kScanBuf * 8 + 64 * 8 + 64 * 4 + 64 * 4);
+	int *bnorm = reinterpret_cast<int *>(lds + (size_t)2 * kScanStage * ROWB);
+	unsigned char *wbase = reinterpret_cast<unsigned char *>(bnorm + 2 * kScanStage) +
+	                       (size_t)wave * (64 * kScanListStride * 8 + 64 * 8 + 64 * 4 + 64 * 4);
 	unsigned long long *list = reinterpret_cast<unsigned long long *>(wbase);
-	unsigned long long *buf = list + 64 * kScanListStride;
-	unsigned long long *thr_s = buf + 64 * kScanBuf;
+	unsigned long long *thr_s = list + 64 * kScanListStride;
 	int *cnt = reinterpret_cast<int *>(thr_s + 64);
 	int *qq_s = cnt + 64;
 
@@ -108,11 +127,11 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 			qf[rt][ks] = v4i{w[0], w[1], w[2], w[3]};
 		}
 	}
+	const int my_qrow = qbase + lane;  // the row this lane owns in the selection structures
 	{  // |q|^2 of row `lane`
-		const int qrow = qbase + lane;
 		int s = 0;
-		if (qrow < a.nq) {
-			const int8_t *src = a.q + (size_t)qrow * (size_t)ix.dim;
+		if (my_qrow < a.nq) {
+			const int8_t *src = a.q + (size_t)my_qrow * (size_t)ix.dim;
 			for (int b = 0; b < ix.dim; b += 4) {
 				const int w = *reinterpret_cast<const int *>(src + b);
 				s = __builtin_amdgcn_sdot4(w, w, s, false);
@@ -122,46 +141,82 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 		cnt[lane] = 0;
 		thr_s[lane] = ~0ull;
 	}
-	int mylen = 0;  // length of row `lane`'s list
-	int qq_r[16];
-	unsigned long long thr_r[16];
+	unsigned long long ext = ~0ull;  // smallest bound other splits published for row `lane`
+	// per lane: the 16 rows its accumulators belong to (the same 16 for the whole quarter-wave):
+	// |q|^2, the 32-bit bound of the fast test and the fill of the row's buffer (kept in step
+	// across the quarter, written to cnt[] only around compactions)
+	int qq_r[16], g_r[16], cnt_r[16];
 #pragma unroll
 	for (int i = 0; i < 16; i++) {
-		const int row = (i >> 2) * 16 + (lane >> 4) * 4 + (i & 3);
-		qq_r[i] = qq_s[row];
-		thr_r[i] = ~0ull;
+		qq_r[i] = qq_s[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
+		g_r[i] = (int)0x80000000;
+		cnt_r[i] = 0;
 	}
-
-	// merge pending candidates of every row: lane r walks row r
-	auto flush_all = [&]() {
-		int n = cnt[lane];
-		if (n > kScanBuf) n = kScanBuf;
-		unsigned long long *L = list + lane * kScanListStride;
-		for (int t = 0; t < n; t++) {
-			const unsigned long long key = buf[lane * kScanBuf + t];
-			if (mylen == a.k && !(key < L[a.k - 1])) continue;
-			int i = mylen == a.k ? a.k - 2 : mylen - 1;
-			while (i >= 0 && L[i] > key) {
-				L[i + 1] = L[i];
-				i--;
-			}
-			L[i + 1] = key;
-			if (mylen < a.k) mylen++;
-		}
-		cnt[lane] = 0;
-		thr_s[lane] = mylen == a.k ? L[a.k - 1] : ~0ull;
+	auto cnt_to_lds = [&]() {
+		if ((lane & 15) == 0) {
 #pragma unroll
-		for (int i = 0; i < 16; i++) thr_r[i] = thr_s[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
+			for (int i = 0; i < 16; i++) cnt[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)] = cnt_r[i];
+		}
+	};
+	auto cnt_from_lds = [&]() {
+#pragma unroll
+		for (int i = 0; i < 16; i++) cnt_r[i] = cnt[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
 	};
 
-	// ---- node tile staging: 32 rows x KS*64 bytes = KS*128 16-byte pieces, KS/2 per thread
-	constexpr int PIECES = KS * 128 / 256;
+	// thr_s (exact 64-bit bound per row, LDS) -> g_r (32-bit fast test, registers)
+	auto refresh_bounds = [&]() {
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			const unsigned long long t = thr_s[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
+			const int tv = (int)((unsigned)(t >> 32) ^ 0x80000000u);
+			int g = (int)0x80000000;
+			if (t != ~0ull) g = a.metric == 0 ? ((qq_r[i] - tv + 1) >> 1) : -tv;
+			g_r[i] = g;
+		}
+	};
+	// Compact the rows in `rows` (bit r = row r) to their best min(n, k) keys, sorted ascending.
+	// Lane j holds key j of the row; its rank is the number of smaller keys (keys are unique).
+	auto compact_rows = [&](unsigned long long rows) {
+		while (rows) {
+			const int R = __builtin_ctzll(rows);
+			rows &= rows - 1;
+			int n = __builtin_amdgcn_readfirstlane(cnt[R]);
+			if (n > kScanCap) n = kScanCap;
+			unsigned long long *L = list + R * kScanListStride;
+			const unsigned long long key = lane < n ? L[lane] : ~0ull;
+			const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+			int rank = 0;
+			for (int i = 0; i < n; i++) {
+				const unsigned long long ki = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)klo, i) |
+				                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, i) << 32);
+				rank += ki < key ? 1 : 0;
+			}
+			if (lane < n && rank < a.k) L[rank] = key;
+			if (lane == 0) cnt[R] = n < a.k ? n : a.k;
+			if (n >= a.k) {
+				const unsigned long long ext_R =
+				    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)ext, R) |
+				    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(ext >> 32), R) << 32);
+				if (lane < n && rank == a.k - 1) {
+					thr_s[R] = key < ext_R ? key : ext_R;
+					if (key < ext_R && qbase + R < a.nq) atomicMin(&a.thr_g[qbase + R], key);
+				}
+			}
+		}
+	};
+
+	// ---- node tile staging: kScanStage rows x KS*64 bytes, KS 16-byte pieces per thread.  The
+	// loads of staged tile T+1 are issued before the two MFMA passes over tile T and stored to
+	// the other LDS buffer after them: two passes (~2 x 1024 matrix-pipe cycles) cover an L2 hit
+	// and most of an HBM miss.  (A register ring of several tiles does not work with hipcc: it
+	// drains vmcnt to zero at the first MFMA of the loop body, i.e. right after the newest load.)
+	constexpr int PIECES = KS * 4 * kScanStage / 256;
 	const int pieces_row = KS * 4;
 	const int row_pieces_valid = ix.row_stride >> 4;
 	int4 stage[PIECES];
 	int stage_norm = -1;
 	auto stage_load = [&](int tile) {
-		const int node0 = n_begin + tile * kScanTN;
+		const int node0 = n_begin + tile * kScanStage;
 #pragma unroll
 		for (int i = 0; i < PIECES; i++) {
 			const int p = tid + 256 * i;
@@ -172,100 +227,203 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 				v = *reinterpret_cast<const int4 *>(ix.vec + (size_t)node * (size_t)ix.row_stride + c * 16);
 			stage[i] = v;
 		}
-		if (tid < kScanTN) {
+		if (tid < kScanStage) {
 			const int node = node0 + tid;
 			stage_norm = node < n_end ? a.norm2[node] : -1;
 		}
 	};
 	auto stage_store = [&](int bufi) {
-		unsigned char *dst = btile + (size_t)bufi * kScanTN * ROWB;
+		unsigned char *dst = btile + (size_t)bufi * kScanStage * ROWB;
 #pragma unroll
 		for (int i = 0; i < PIECES; i++) {
 			const int p = tid + 256 * i;
 			const int r = p / pieces_row, c = p % pieces_row;
 			*reinterpret_cast<int4 *>(dst + r * ROWB + c * 16) = stage[i];
 		}
-		if (tid < kScanTN) bnorm[bufi * kScanTN + tid] = stage_norm;
+		if (tid < kScanStage) bnorm[bufi * kScanStage + tid] = stage_norm;
 	};
 
+#ifdef MVDB_SCAN_DEBUG
+	unsigned long long dbg_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+	// The (rare) elements that pass the fast test are appended to their row's buffer.  C[row][col]:
+	// col = lane & 15 (node), row = (lane >> 4) * 4 + reg (query); vn0/vn1 = norms of this lane's
+	// two columns; anyg[j] != 0 when some lane passed the test for an element in [8j, 8j+8).
+	auto slow_path = [&](const v4i (&acc)[4][2], int node0, int vn0, int vn1, const unsigned long long (&anyg)[4]) {
+#ifdef MVDB_SCAN_DEBUG
+		const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+		dbg_c[1]++;
+#endif
+		unsigned pend = 0;
+#pragma unroll
+		for (int gi = 0; gi < 4; gi++) {
+			if (anyg[gi]) {
+#pragma unroll
+				for (int e = gi * 8; e < gi * 8 + 8; e++)
+					pend |= (acc[(e & 15) >> 2][e >> 4][e & 3] >= g_r[e & 15]) ? (1u << e) : 0u;
+			}
+		}
+		if (vn0 < 0) pend &= 0xffff0000u;
+		if (vn1 < 0) pend &= 0x0000ffffu;
+		while (__ballot(pend != 0)) {
+			bool ovf = false;
+#pragma unroll
+			for (int gi = 0; gi < 4; gi++) {
+				if (__ballot((pend >> (gi * 8)) & 0xffu)) {
+#pragma unroll
+					for (int e = gi * 8; e < gi * 8 + 8; e++) {
+						const bool pe = (pend >> e) & 1u;
+						const unsigned long long m = __ballot(pe);
+						if (m) {
+							// the 16 lanes of a quarter-wave hold 16 columns of the SAME row: slots by prefix count
+							const int i = e & 15, ct = e >> 4;
+							const unsigned qm = (unsigned)(m >> (lane & 48)) & 0xffffu;
+							const int slot = cnt_r[i] + __builtin_popcount(qm & ((1u << (lane & 15)) - 1u));
+							const int nc = cnt_r[i] + __builtin_popcount(qm);
+							if (pe && slot < kScanCap) {
+								const int row = (i >> 2) * 16 + (lane >> 4) * 4 + (i & 3);
+								const int vn = ct ? vn1 : vn0;
+								const int av = acc[i >> 2][ct][i & 3];
+								const int c = a.metric == 0 ? av + (vn >> 1) : av;
+								const int val = a.metric == 0 ? qq_r[i] + vn - 2 * c : -c;
+								list[row * kScanListStride + slot] = scan_key(val, node0 + ct * 16 + (lane & 15));
+								pend &= ~(1u << e);
+							}
+							ovf |= nc >= kScanCap;
+							cnt_r[i] = nc < kScanCap ? nc : kScanCap;
+						}
+					}
+				}
+			}
+#ifdef MVDB_SCAN_DEBUG
+			dbg_c[2]++;
+#endif
+			if (__ballot(ovf)) {  // a full buffer keeps its element pending: compact, tighten the bounds, retry
+				cnt_to_lds();
+				const unsigned long long full = __ballot(cnt[lane] >= kScanCap);
+#ifdef MVDB_SCAN_DEBUG
+				dbg_c[3] += __builtin_popcountll(full);
+#endif
+				compact_rows(full);
+				cnt_from_lds();
+				refresh_bounds();
+			}
+		}
+#ifdef MVDB_SCAN_DEBUG
+		dbg_c[4] += __builtin_amdgcn_s_memtime() - t_in;
+#endif
+	};
+	auto col_init = [&](int vn) -> int { return vn < 0 ? -(1 << 30) : (a.metric == 0 ? -(vn >> 1) : 0); };
+
+	// Software pipeline: the MFMAs of tile t are issued together with the fast test of tile t-1
+	// (independent instruction streams, one matrix-pipe and one VALU), the rare slow path follows.
+	v4i accA[4][2], accB[4][2];
+#pragma unroll
+	for (int rt = 0; rt < 4; rt++) accB[rt][0] = accB[rt][1] = v4i{0, 0, 0, 0};
+	int pvn0 = -1, pvn1 = -1, pnode0 = 0;
+	bool have_prev = false;
+	unsigned long long ext_next = ~0ull;
 	if (ntiles > 0) {
 		stage_load(0);
 		stage_store(0);
 	}
 	__syncthreads();
 
-	for (int tile = 0; tile < ntiles; tile++) {
-		const int cur = tile & 1;
-		if (tile + 1 < ntiles) stage_load(tile + 1);  // in flight under the MFMAs
-
-		const unsigned char *bt = btile + (size_t)cur * kScanTN * ROWB;
-		v4i acc[4][2];
+	// one MFMA pass over 32 staged rows (half `half` of buffer `cur`) into accN, with the fast test
+	// of the previous pass (accP) riding along
+	auto pass = [&](int tile, int cur, int half, v4i (&accN)[4][2], const v4i (&accP)[4][2]) {
+		const unsigned char *bt = btile + ((size_t)cur * kScanStage + half * kScanTN) * ROWB;
+		const int *bn = bnorm + cur * kScanStage + half * kScanTN;
+		const int vn0 = bn[lane & 15], vn1 = bn[16 + (lane & 15)];
+		const int c0 = col_init(vn0), c1 = col_init(vn1);
 #pragma unroll
-		for (int rt = 0; rt < 4; rt++) acc[rt][0] = acc[rt][1] = v4i{0, 0, 0, 0};
+		for (int rt = 0; rt < 4; rt++) {
+			accN[rt][0] = v4i{c0, c0, c0, c0};
+			accN[rt][1] = v4i{c1, c1, c1, c1};
+		}
+		unsigned long long anyg[4] = {0, 0, 0, 0};
+		const unsigned char *bp0 = bt + (lane & 15) * ROWB + (lane >> 4) * 16;
+		const unsigned char *bp1 = bp0 + 16 * ROWB;
+		// fragments of k-steps ks+1 and ks+2 are in flight while the MFMAs of ks run
+		v4i bf[KS + 2][2];
+		bf[0][0] = *reinterpret_cast<const v4i *>(bp0);
+		bf[0][1] = *reinterpret_cast<const v4i *>(bp1);
+		bf[1][0] = *reinterpret_cast<const v4i *>(bp0 + 64);
+		bf[1][1] = *reinterpret_cast<const v4i *>(bp1 + 64);
+		constexpr int PER = 32 / (KS * 4);
 #pragma unroll
 		for (int ks = 0; ks < KS; ks++) {
-			const int coff = (ks * 4 + (lane >> 4)) * 16;
-			const v4i b0 = *reinterpret_cast<const v4i *>(bt + (lane & 15) * ROWB + coff);
-			const v4i b1 = *reinterpret_cast<const v4i *>(bt + ((lane & 15) + 16) * ROWB + coff);
+			if (ks + 2 < KS) {
+				bf[ks + 2][0] = *reinterpret_cast<const v4i *>(bp0 + (ks + 2) * 64);
+				bf[ks + 2][1] = *reinterpret_cast<const v4i *>(bp1 + (ks + 2) * 64);
+			}
 #pragma unroll
 			for (int rt = 0; rt < 4; rt++) {
-				acc[rt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], b0, acc[rt][0], 0, 0, 0);
-				acc[rt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], b1, acc[rt][1], 0, 0, 0);
-			}
-		}
-
-		// ---- epilogue: C[row][col]: col = lane & 15 (node), row = (lane >> 4) * 4 + reg (query)
-		unsigned long long pend_key[32];
-		unsigned pend_mask = 0;
+				accN[rt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], bf[ks][0], accN[rt][0], 0, 0, 0);
+				accN[rt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], bf[ks][1], accN[rt][1], 0, 0, 0);
 #pragma unroll
-		for (int ct = 0; ct < 2; ct++) {
-			const int col = ct * 16 + (lane & 15);
-			const int node = n_begin + tile * kScanTN + col;
-			const int vn = bnorm[cur * kScanTN + col];
-#pragma unroll
-			for (int i = 0; i < 16; i++) {
-				const int c = acc[i >> 2][ct][i & 3];
-				const int val = a.metric == 0 ? qq_r[i] + vn - 2 * c : -c;
-				const unsigned long long key = scan_key(val, node);
-				pend_key[ct * 16 + i] = key;
-				if (vn >= 0 && key < thr_r[i]) pend_mask |= 1u << (ct * 16 + i);
-			}
-		}
-		while (__ballot(pend_mask != 0)) {
-#pragma unroll
-			for (int e = 0; e < 32; e++) {
-				if (pend_mask & (1u << e)) {
-					const int i = e & 15;
-					const int row = (i >> 2) * 16 + (lane >> 4) * 4 + (i & 3);
-					if (!(pend_key[e] < thr_r[i])) {
-						pend_mask &= ~(1u << e);  // no longer a candidate after a flush
-					} else {
-						const int slot = atomicAdd(&cnt[row], 1);
-						if (slot < kScanBuf) {
-							buf[row * kScanBuf + slot] = pend_key[e];
-							pend_mask &= ~(1u << e);
-						}
-					}
+				for (int u = 0; u < PER; u++) {
+					const int e = (ks * 4 + rt) * PER + u;
+					anyg[e >> 3] |= __ballot(accP[(e & 15) >> 2][e >> 4][e & 3] >= g_r[e & 15]);
 				}
 			}
-			// flush when something is still pending or a buffer is half full
-			if (__ballot(pend_mask != 0 || cnt[lane] >= kScanBuf / 2)) flush_all();
+			__builtin_amdgcn_sched_barrier(0);
 		}
-
+#pragma unroll
+		for (int e = PER * KS * 4; e < 32; e++)
+			anyg[e >> 3] |= __ballot(accP[(e & 15) >> 2][e >> 4][e & 3] >= g_r[e & 15]);
+		if (have_prev && (anyg[0] | anyg[1] | anyg[2] | anyg[3])) slow_path(accP, pnode0, pvn0, pvn1, anyg);
+		pvn0 = vn0;
+		pvn1 = vn1;
+		pnode0 = n_begin + tile * kScanStage + half * kScanTN;
+		have_prev = true;
+#ifdef MVDB_SCAN_DEBUG
+		dbg_c[0]++;
+#endif
+	};
+	for (int tile = 0; tile < ntiles; tile++) {
+		const int cur = tile & 1;
+		if (tile + 1 < ntiles) stage_load(tile + 1);  // in flight under both passes
+		if ((tile % kScanPoll) == 0 && my_qrow < a.nq)
+			ext_next = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		pass(tile, cur, 0, accA, accB);
+		pass(tile, cur, 1, accB, accA);
+		if ((tile % kScanPoll) == 1 && ext_next < ext) {  // a tighter bound from another split
+			ext = ext_next;
+			if (ext < thr_s[lane]) thr_s[lane] = ext;
+			refresh_bounds();
+		}
+#ifdef MVDB_SCAN_DEBUG
+		const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+#endif
 		if (tile + 1 < ntiles) stage_store(cur ^ 1);
 		__syncthreads();
+#ifdef MVDB_SCAN_DEBUG
+		dbg_c[5] += __builtin_amdgcn_s_memtime() - t_b;
+#endif
 	}
-	flush_all();
+	if (have_prev) {  // the last pass always ran into accB
+		unsigned long long anyg[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int e = 0; e < 32; e++) anyg[e >> 3] |= __ballot(accB[(e & 15) >> 2][e >> 4][e & 3] >= g_r[e & 15]);
+		if (anyg[0] | anyg[1] | anyg[2] | anyg[3]) slow_path(accB, pnode0, pvn0, pvn1, anyg);
+	}
+	cnt_to_lds();
+	compact_rows(__ballot(cnt[lane] > 0));  // every row: best min(n, k), sorted
+#ifdef MVDB_SCAN_DEBUG
+	dbg_c[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
+	if (lane == 0 && a.dbg)
+		for (int i = 0; i < 8; i++) atomicAdd(&a.dbg[i], dbg_c[i]);
+#endif
 
-	// ---- per-(query, split) partial lists
-	{
-		const int qrow = qbase + lane;
-		if (qrow < a.nq) {
-			const size_t o = ((size_t)qrow * a.nsplit + split) * (size_t)a.k;
-			const unsigned long long *L = list + lane * kScanListStride;
-			for (int i = 0; i < mylen; i++) a.part_key[o + i] = L[i];
-			a.part_n[(size_t)qrow * a.nsplit + split] = mylen;
-		}
+	// ---- per-(query, split) partial lists, sorted ascending
+	if (my_qrow < a.nq) {
+		const unsigned long long *L = list + lane * kScanListStride;
+		const int mylen = cnt[lane];
+		const size_t o = ((size_t)my_qrow * a.nsplit + split) * (size_t)a.k;
+		for (int i = 0; i < mylen; i++) a.part_key[o + i] = L[i];
+		a.part_n[(size_t)my_qrow * a.nsplit + split] = mylen;
 	}
 }
 
@@ -310,6 +468,42 @@ __global__ void scan_merge_kernel(ScanArgs a)
 	}
 }
 
+// Warm start (see launch_scan): after a sweep over a prefix of the nodes, thr_g[q] = (k-th smallest
+// key of the prefix) + 1 -- "k keys below this bound exist".  +1 because the full sweep visits the
+// prefix again and must still accept that very key (keys are unique: value << 32 | id).
+__global__ void scan_bound_kernel(ScanArgs a)
+{
+	const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (qi >= a.nq) return;
+	const unsigned long long *pk = a.part_key + (size_t)qi * a.nsplit * a.k;
+	const int32_t *pn = a.part_n + (size_t)qi * a.nsplit;
+	unsigned long long last = 0;
+	bool have_last = false;
+	int out = 0;
+	for (; out < a.k; out++) {
+		unsigned long long best = ~0ull;
+		bool found = false;
+		for (int s = 0; s < a.nsplit; s++) {
+			const int n = pn[s];
+			for (int i = 0; i < n; i++) {
+				const unsigned long long key = pk[(size_t)s * a.k + i];
+				if (have_last && key <= last) continue;
+				if (!found || key < best) {
+					best = key;
+					found = true;
+				}
+				break;
+			}
+		}
+		if (!found) break;
+		last = best;
+		have_last = true;
+	}
+	a.thr_g[qi] = out == a.k ? last + 1 : ~0ull;
+}
+
+constexpr int kScanWarmNodes = 8192;  // prefix swept first to seed the bounds
+
 template <int KS>
 inline bool launch_scan_t(const ScanArgs &a, hipStream_t s)
 {
@@ -317,6 +511,16 @@ inline bool launch_scan_t(const ScanArgs &a, hipStream_t s)
 	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KS>),
 	                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
 		return false;
+	// Most candidates of a sweep turn up in its first few thousand nodes, when the bounds are
+	// still loose and every split learns them separately.  Sweeping a short prefix first and
+	// starting the full sweep from its k-th keys removes ~90 % of the slow-path entries.
+	if (a.ix.max_elements >= 8 * kScanWarmNodes) {
+		ScanArgs w = a;
+		w.ix.max_elements = kScanWarmNodes;
+		w.nodes_per_split = (((kScanWarmNodes + w.nsplit - 1) / w.nsplit) + kScanStage - 1) / kScanStage * kScanStage;
+		hipLaunchKernelGGL((scan_kernel<KS>), dim3(w.qtiles * w.nsplit), dim3(256), lds, s, w);
+		hipLaunchKernelGGL(scan_bound_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, s, w);
+	}
 	hipLaunchKernelGGL((scan_kernel<KS>), dim3(a.qtiles * a.nsplit), dim3(256), lds, s, a);
 	hipLaunchKernelGGL(scan_merge_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError() == hipSuccess;
