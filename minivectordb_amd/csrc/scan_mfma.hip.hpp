@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 							if (pe && slot < kScanCap) {
 								const int row = (i >> 2) * 16 + (lane >> 4) * 4 + (i & 3);
 								const int vn = ct ? vn1 : vn0;
-								const int av = acc[i >> 2][ct][i & 3];
+								int av = acc[i >> 2][ct][i & 3];
+								// keep the key arithmetic inside this (rarely taken) branch: without the barrier
+								// hipcc hoists all 32 keys out of the retry loop and pays for them on every entry
+								asm volatile("" : "+v"(av));
 								const int c = a.metric == 0 ? av + (vn >> 1) : av;
 								const int val = a.metric == 0 ? qq_r[i] + vn - 2 * c : -c;
 								list[row * kScanListStride + slot] = scan_key(val, node0 + ct * 16 + (lane & 15));
@@ -305,9 +308,15 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 #ifdef MVDB_SCAN_DEBUG
 				dbg_c[3] += __builtin_popcountll(full);
 #endif
+#ifdef MVDB_SCAN_DEBUG
+				const unsigned long long t_c = __builtin_amdgcn_s_memtime();
+#endif
 				compact_rows(full);
 				cnt_from_lds();
 				refresh_bounds();
+#ifdef MVDB_SCAN_DEBUG
+				dbg_c[7] += __builtin_amdgcn_s_memtime() - t_c;
+#endif
 			}
 		}
 #ifdef MVDB_SCAN_DEBUG
@@ -328,7 +337,11 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 		stage_load(0);
 		stage_store(0);
 	}
+	// bounds known before the sweep starts (the warm-start launch, or splits that are ahead)
+	if (my_qrow < a.nq) ext = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	thr_s[lane] = ext;
 	__syncthreads();
+	refresh_bounds();
 
 	// one MFMA pass over 32 staged rows (half `half` of buffer `cur`) into accN, with the fast test
 	// of the previous pass (accP) riding along

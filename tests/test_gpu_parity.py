@@ -146,3 +146,26 @@ def test_scan_many_bit_exact(small):
             assert np.array_equal(gc, oc)
             assert np.array_equal(gi, oi), (metric, k)
             assert np.array_equal(gv, ov), (metric, k)
+
+
+def test_scan_many_large_with_gaps(gpu):
+    """Large enough for the warm-start prefix sweep and the cross-split bound exchange (>= 65536 slots),
+    with absent ids (gaps) and heavy value ties (coarse coordinates), k up to the kernel's maximum."""
+    from minivectordb_amd import HipBridge
+    n_slots, dim = 90000, 64
+    rng = np.random.default_rng(31)
+    ids = np.sort(rng.choice(n_slots, size=80000, replace=False)).astype(np.int32)
+    b8 = (rng.integers(-3, 4, (ids.size, dim)) * 40).astype(np.int8)  # 7 distinct values per coordinate: many ties
+    ix = O.OracleIndex(dim, 2, 4, n_slots, seed=5)
+    ix.insert_many(ids, b8)
+    b = HipBridge()
+    b.init(dict(dim=dim, m=2, ef=4, capacity=8, seed=1))
+    b.loadBytes(ix.save_bytes())
+    q8 = (rng.integers(-3, 4, (333, dim)) * 40).astype(np.int8)
+    for metric in ("l2", "dot"):
+        for k in (1, 10, 32):
+            gi, gv, gc = b.scanMany(q8, k, metric)
+            oi, ov, oc = ix.scan_many(q8, k, metric, threads=8)
+            assert np.array_equal(gc, oc)
+            assert np.array_equal(gi, oi), (metric, k)
+            assert np.array_equal(gv, ov), (metric, k)

@@ -27,7 +27,9 @@ out = np.zeros(8, np.uint64)
 L = b._L
 L.mvdb_debug_scan_counters.argtypes = [C.c_void_p, C.c_void_p]
 assert L.mvdb_debug_scan_counters(b.handle, out.ctypes.data_as(C.c_void_p))
-tiles, entries, iters, rows_flushed, slow_cyc, store_barrier_cyc, total_cyc = (int(x) for x in out[:7])
+tiles, entries, iters, rows_flushed, slow_cyc, store_barrier_cyc, total_cyc, compact_cyc = (int(x) for x in out[:8])
+print(f"compaction + refresh: {100 * compact_cyc / total_cyc:.1f}% of wave cycles, {compact_cyc / max(rows_flushed, 1):.0f} cycles per compacted row; "
+      f"rest of slow path {(slow_cyc - compact_cyc) / max(entries, 1):.0f} cycles per entry")
 print(f"wave-tiles {tiles}  slow-path entries {entries} ({entries / max(tiles, 1):.3f}/tile)  loop iterations {iters}")
 print(f"row compactions {rows_flushed} ({rows_flushed / max(tiles, 1):.3f}/tile)")
 print(f"wave cycles: total {total_cyc:.3g}  slow path {100 * slow_cyc / total_cyc:.1f}%  "
