@@ -55,8 +55,10 @@ def main():
         ops = 2.0 * nq * rows * dim
         out[metric] = {"ms": ms, "TOPs": ops / (ms * 1e-3) / 1e12, "qps": nq / (ms * 1e-3),
                        "hbm_floor_ms": rows * dim / 8e12 * 1e3}
-        ns = min(nq, 8)
+        ns = min(nq, 32)
+        t0 = time.perf_counter()
         o_ids, o_val, o_cnt = ix.scan_many(q8[:ns], k, metric, threads=16)
+        out[metric]["cpu_oracle_qps_16thr"] = ns / (time.perf_counter() - t0)
         out[metric]["parity_sample_ok"] = bool(np.array_equal(o_ids, ids[:ns]) and np.array_equal(o_val, val[:ns])
                                                and np.array_equal(o_cnt, cnt[:ns]))
     print(json.dumps(out))
