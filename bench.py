@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--build-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="batch i's rerank on a second stream under batch i+1's traversal (measured slower on "
+                         "MI355X: 4.52 vs 4.34 ms per batch, DESIGN.md 4.1; default: one batch at a time)")
     args = ap.parse_args()
 
     import torch
@@ -155,10 +158,20 @@ def main():
     searcher = ResidentSearcher(bridge, nq, tk, dev)
     id_offset = rank * N if sharded else 0
 
+    pipelined = args.pipeline
+    if pipelined:
+        os.environ.setdefault("MVDB_RERANK_WAVES", "2")  # rerank workgroups that fit beside a running traversal
+
     def step():
-        ids, l2, n = searcher.query_many(q_dev, ef_search, ann_k)
-        if world == 1:
-            return ids, l2, n
+        if pipelined:
+            slot, ids, l2, n = searcher.submit(q_dev, ef_search, ann_k)
+            if world == 1:
+                return ids, l2, n
+            searcher.wait(slot)
+        else:
+            ids, l2, n = searcher.query_many(q_dev, ef_search, ann_k)
+            if world == 1:
+                return ids, l2, n
         if sharded:
             gid = ids + id_offset if id_offset else ids
             all_ids, all_l2, all_n = gather_topk(gid, l2, n)          # the one exchange step (RCCL all-gather)
@@ -170,6 +183,8 @@ def main():
     log(f"rank {rank}: warmup {args.warmup} steps (first step uploads the index)")
     for _ in range(args.warmup):
         step()
+    if pipelined:
+        searcher.drain()
     torch.cuda.synchronize(dev)
     bridge._L.mvdb_enable_timing(bridge.handle, 1)
     searcher.stage_stats(0), searcher.stage_stats(1), searcher.stage_stats(2)
@@ -178,7 +193,9 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last = step()
+    if pipelined:
+        searcher.drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -228,6 +245,10 @@ def main():
     ids_dev, l2_dev, n_dev = searcher.query_many(q_dev, ef_search, ann_k)
     torch.cuda.synchronize(dev)
     got = ids_dev.cpu().numpy()
+    if pipelined and world == 1:  # the pipelined batches answered the same queries: same bits expected
+        p_ids, p_l2, p_n = last
+        assert torch.equal(p_ids, ids_dev) and torch.equal(p_l2, l2_dev) and torch.equal(p_n, n_dev), \
+            "pipelined and single-stream results differ"
     if not args.no_recall and rank == 0:
         qn_host, _ = bridge.prepareQueries(q_host)
         qn = torch.from_numpy(qn_host).to(dev)
@@ -283,6 +304,8 @@ def main():
                                         f"batch {nq} queries, topK={tk}",
                                n=N, dim=dim, nq=nq, topk=tk, ann_k=ann_k, preset=args.preset,
                                mode=("single" if world == 1 else args.mode),
+                               batches=("pipelined: rerank of batch i on a second stream under the traversal "
+                                        "of batch i+1" if pipelined else "one at a time"),
                                graph="engine parallel builder (reference insert algorithm, unordered)"),
                    recall_at_10=None if recall is None else round(recall, 4),
                    roofline=roofline, cpu_baseline=cpu_baseline,

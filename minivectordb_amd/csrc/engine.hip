@@ -268,7 +268,9 @@ struct StageTimer {
 	{
 		if (!h->timing) return;
 		hipEvent_t e0 = nullptr;
-		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+		if (hipEventCreate(&e0) != hipSuccess) return;
+		if (hipEventCreate(&e1) != hipSuccess) {
+			(void)hipEventDestroy(e0);
 			e1 = nullptr;
 			return;
 		}
@@ -643,15 +645,20 @@ int mvdb_rerank_many_dev(mvdb_index *h, const float *d_q_f32, int nq, const int3
 	a.out_l2 = d_out_l2;
 	a.out_n = d_out_n;
 	const int cap = std::min(stride, ann_k);
-	const size_t lds = rerank_lds_bytes(a.dim, cap);
+	// MVDB_RERANK_WAVES=2: small workgroups that fit beside a running traversal (pipelined batches)
+	const char *rw = std::getenv("MVDB_RERANK_WAVES");
+	const int waves = (rw && std::atoi(rw) == 2) ? 2 : kRerankWavesDefault;
+	const size_t lds = rerank_lds_bytes(a.dim, cap, waves);
 	if (lds > 160 * 1024) {
 		h->set_error("rerank: candidate list too long for LDS");
 		return 0;
 	}
-	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&rerank_kernel),
-	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	const void *fn = waves == 2 ? reinterpret_cast<const void *>(&rerank_kernel<2>)
+	                            : reinterpret_cast<const void *>(&rerank_kernel<kRerankWavesDefault>);
+	HIP_OK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	StageTimer t(h, 2, s);
-	hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(kRerankThreads), lds, s, a, cap);
+	if (waves == 2) hipLaunchKernelGGL(rerank_kernel<2>, dim3(nq), dim3(128), lds, s, a, cap);
+	else hipLaunchKernelGGL(rerank_kernel<kRerankWavesDefault>, dim3(nq), dim3(kRerankWavesDefault * 64), lds, s, a, cap);
 	HIP_OK(h, hipGetLastError());
 	return 1;
 }

@@ -19,8 +19,9 @@
 
 namespace mvdb {
 
-constexpr int kRerankThreads = 256;
-constexpr int kRerankWaves = kRerankThreads / 64;
+// waves per workgroup: 4 by default; 2 when the rerank is meant to share CUs with a running
+// traversal (34 KB of LDS instead of 53 KB: it then fits beside four traversal workgroups)
+constexpr int kRerankWavesDefault = 4;
 #ifndef MVDB_RERANK_TILE_COLS
 #define MVDB_RERANK_TILE_COLS 32
 #endif
@@ -49,8 +50,8 @@ struct RerankArgs {
 	int32_t *out_n;           // nq
 };
 
-// LDS: q_s[dim_pad] f32 | tiles[kRerankWaves][64*144] | key_l2[cap] f64 | key_id[cap] i32 | misc
-__host__ __device__ inline size_t rerank_lds_bytes(int dim, int cap)
+// LDS: q_s[dim_pad] f32 | tiles[waves][64*144] | key_l2[cap] f64 | key_id[cap] i32 | misc
+__host__ __device__ inline size_t rerank_lds_bytes(int dim, int cap, int kRerankWaves = kRerankWavesDefault)
 {
 	size_t dim_pad = ((size_t)dim + kTileCols - 1) / kTileCols * kTileCols;
 	size_t b = dim_pad * 4;
@@ -70,9 +71,11 @@ __device__ __forceinline__ bool key_less(double al2, int aid, double bl2, int bi
 	return al2 < bl2 || (al2 == bl2 && aid < bid);  // :637  a.l2 - b.l2 || a.id - b.id
 }
 
-__global__ __launch_bounds__(kRerankThreads) void rerank_kernel(RerankArgs a, int cap)
+template <int kRerankWaves>
+__global__ __launch_bounds__(kRerankWaves * 64) void rerank_kernel(RerankArgs a, int cap)
 {
 #pragma clang fp contract(off)
+	constexpr int kRerankThreads = kRerankWaves * 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int qi = blockIdx.x;

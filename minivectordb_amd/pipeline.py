@@ -39,6 +39,79 @@ class ResidentSearcher:
         self.b._check(ok)
         return self.out_ids[:nq], self.out_l2[:nq], self.out_n[:nq]
 
+    # ---- consecutive batches, software-pipelined ---------------------------------------------
+    # The traversal is latency-bound and leaves HBM idle; the rerank is bandwidth-bound.  With
+    # batch i's rerank on a second stream, it runs under batch i+1's traversal (set
+    # MVDB_RERANK_WAVES=2 so that a rerank workgroup fits beside four traversal workgroups on a
+    # CU).  Results of a submitted batch are valid after `wait(slot)`/`drain()`.
+    def _pipe_init(self, nq: int, dim: int, ann_k: int):
+        key = (nq, dim, ann_k)
+        if getattr(self, "_pipe_key", None) == key:
+            return
+        dev = self.device
+        self._pipe_key = key
+        self._pipe_i = 0
+        # the traversal needs all its workgroups resident at once (it is latency-bound): its stream gets
+        # the high priority so that a ready rerank never takes their place at dispatch
+        self._t_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self._r_stream = torch.cuda.Stream(device=dev, priority=0)
+        self._slots = []
+        for _ in range(2):
+            self._slots.append(dict(
+                qf=torch.empty((nq, dim), dtype=torch.float32, device=dev),
+                q8=torch.empty((nq, dim), dtype=torch.int8, device=dev),
+                cand=torch.empty((nq, max(ann_k, 1)), dtype=torch.int32, device=dev),
+                dist=torch.empty((nq, max(ann_k, 1)), dtype=torch.float32, device=dev),
+                cnt=torch.empty((nq,), dtype=torch.int32, device=dev),
+                ctr=torch.zeros((nq, 4), dtype=torch.int32, device=dev),
+                ids=torch.empty((nq, self.topk), dtype=torch.int32, device=dev),
+                l2=torch.empty((nq, self.topk), dtype=torch.float64, device=dev),
+                n=torch.empty((nq,), dtype=torch.int32, device=dev),
+                ready=torch.cuda.Event(), done=torch.cuda.Event(), used=False))
+
+    def submit(self, q_f32: torch.Tensor, ef_search: int, ann_k: int, allow: torch.Tensor | None = None):
+        """Enqueue one batch; returns (slot, ids, l2, n) -- tensors are valid after wait(slot)."""
+        assert q_f32.is_cuda and q_f32.dtype == torch.float32 and q_f32.is_contiguous()
+        nq, dim = q_f32.shape
+        self._pipe_init(nq, dim, int(ann_k))
+        slot = self._pipe_i & 1
+        self._pipe_i += 1
+        s = self._slots[slot]
+        L, h = self.L, self.h
+        L.mvdb_set_ef_search(h, int(ef_search))                    # mini-vector-db.ts:572
+        L.mvdb_ensure_results_cap_at_least(h, int(ann_k))          # :577
+        cur = torch.cuda.current_stream(self.device)
+        T, R = self._t_stream, self._r_stream
+        T.wait_stream(cur)                       # the queries were produced on the caller's stream
+        if s["used"]:
+            T.wait_event(s["done"])              # the rerank two batches ago still reads this slot
+        vp = C.c_void_p
+        self.b._check(L.mvdb_prepare_queries_dev(h, vp(q_f32.data_ptr()), nq, vp(s["qf"].data_ptr()),
+                                                 vp(s["q8"].data_ptr()), vp(T.cuda_stream)))
+        self.b._check(L.mvdb_search_many_dev(h, vp(s["q8"].data_ptr()), nq, int(ann_k), vp(s["cand"].data_ptr()),
+                                             vp(s["dist"].data_ptr()), vp(s["cnt"].data_ptr()),
+                                             vp(s["ctr"].data_ptr()), vp(T.cuda_stream)))
+        s["ready"].record(T)
+        R.wait_event(s["ready"])
+        self.b._check(L.mvdb_rerank_many_dev(h, vp(s["qf"].data_ptr()), nq, vp(s["cand"].data_ptr()),
+                                             vp(s["cnt"].data_ptr()), max(int(ann_k), 1), int(ann_k),
+                                             vp(allow.data_ptr()) if allow is not None else None, self.topk,
+                                             vp(s["ids"].data_ptr()), vp(s["l2"].data_ptr()), vp(s["n"].data_ptr()),
+                                             vp(R.cuda_stream)))
+        s["done"].record(R)
+        s["used"] = True
+        self.ctr = s["ctr"]
+        return slot, s["ids"], s["l2"], s["n"]
+
+    def wait(self, slot: int):
+        """Make the caller's current stream wait for the batch in `slot`."""
+        torch.cuda.current_stream(self.device).wait_event(self._slots[slot]["done"])
+
+    def drain(self):
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self._t_stream)
+        cur.wait_stream(self._r_stream)
+
     def merge_topk(self, ids: torch.Tensor, l2: torch.Tensor, n: torch.Tensor, parts: int, nq: int):
         """Merge [parts][nq][topk] per-shard results by (l2, id)."""
         out_ids = torch.empty((nq, self.topk), dtype=torch.int32, device=self.device)

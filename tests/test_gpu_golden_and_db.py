@@ -199,3 +199,37 @@ def test_node_napi_bridge(gpu):
     r = subprocess.run(["node", os.path.join(root, "node", "test_bridge.js")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "node bridge test passed" in r.stdout
+
+
+def test_pipelined_batches_equal_single_stream(gpu):
+    """ResidentSearcher.submit (traversal and rerank of consecutive batches on two streams, small rerank
+    workgroups) returns the same bits as query_many, batch after batch, with buffers reused."""
+    import os
+    import torch
+    from minivectordb_amd.pipeline import ResidentSearcher
+    from tests._data import bridge_from_dump, built_index, gaussian_unit
+    dump, base, b8 = built_index(4000, 384, "balanced")
+    b = bridge_from_dump(dump, 384, "balanced")
+    b.attachF32(base, resident=True)
+    dev = torch.device("cuda", 0)
+    s = ResidentSearcher(b, 200, 10, dev)
+    old = os.environ.get("MVDB_RERANK_WAVES")
+    os.environ["MVDB_RERANK_WAVES"] = "2"
+    try:
+        batches = [torch.from_numpy(gaussian_unit(200, 384, 100 + i)).to(dev) for i in range(5)]
+        outs = []
+        for q in batches:
+            slot, ids, l2, n = s.submit(q, 140, 1200)
+            s.wait(slot)
+            outs.append((ids.clone(), l2.clone(), n.clone()))  # on the current stream, after the wait
+        s.drain()
+        torch.cuda.synchronize(dev)
+    finally:
+        if old is None:
+            os.environ.pop("MVDB_RERANK_WAVES", None)
+        else:
+            os.environ["MVDB_RERANK_WAVES"] = old
+    for q, (ids, l2, n) in zip(batches, outs):
+        r_ids, r_l2, r_n = s.query_many(q, 140, 1200)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(ids, r_ids) and torch.equal(l2, r_l2) and torch.equal(n, r_n)
