@@ -514,8 +514,13 @@ int mvdb_prepare_queries(mvdb_index *h, const float *q_in, int nq, float *q_norm
 }
 
 // ---- stage 1
-int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids, float *d_out_dist,
-                         int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream)
+}  // extern "C"
+
+namespace {
+// shared by mvdb_search_many_dev (sorted lists, the bridge contract) and the fused query path
+// (set_only: see TraverseArgs)
+int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids, float *d_out_dist,
+                         int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream, bool set_only)
 {
 	if (!ensure_uploaded(h)) return 0;
 	if (nq <= 0) return 1;
@@ -543,6 +548,7 @@ int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	a.ef = ef;
 	a.cand_cap = cand_cap;
 	a.results_cap = g.results_cap;
+	a.set_only = set_only ? 1 : 0;
 	a.vis_words = ((size_t)g.max_elements + 31) / 32;
 	// visited bitmaps: bounded scratch, queries are processed in slabs
 	const size_t slab_bytes_max = (size_t)2 << 30;
@@ -570,6 +576,15 @@ int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		if (!launch_traverse(h, a, s)) return 0;
 	}
 	return 1;
+}
+}  // namespace
+
+extern "C" {
+
+int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids, float *d_out_dist,
+                         int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream)
+{
+	return search_many_dev_impl(h, d_q, nq, k, d_out_ids, d_out_dist, d_out_count, d_ctr, stream, false);
 }
 
 int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out_ids, float *out_dist,
@@ -760,7 +775,8 @@ int mvdb_query_many_dev(mvdb_index *h, const float *d_q_f32, int nq, int topk, i
 		return 0;
 	}
 	if (!mvdb_prepare_queries_dev(h, d_q_f32, nq, d_qf, d_q8, stream)) return 0;               // :582-591
-	if (!mvdb_search_many_dev(h, d_q8, nq, ann_k, d_ids, d_dist, d_cnt, d_ctr, stream)) return 0;  // :593
+	// :593; the rerank below keeps every candidate when none is cut off, so their order is irrelevant
+	if (!search_many_dev_impl(h, d_q8, nq, ann_k, d_ids, d_dist, d_cnt, d_ctr, stream, true)) return 0;
 	return mvdb_rerank_many_dev(h, d_qf, nq, d_ids, d_cnt, ak, ann_k, d_allow, topk, d_out_ids, d_out_l2, d_out_n,
 	                            stream);                                                       // :606-651
 }

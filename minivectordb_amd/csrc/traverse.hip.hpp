@@ -273,10 +273,17 @@ __device__ __forceinline__ void dist_rows(const DevIndexView &ix, const QueryReg
 }
 
 // ---- the kernel --------------------------------------------------------------------
+// Output order.  search() returns the result heap sorted by repeated pops (hnsw.ts:317-325, ~13 % of
+// the kernel).  The fused query path (mini-vector-db.ts:595-651) consumes the list as a SET whenever
+// nothing is cut off: the filter keeps the first annK candidates in ANN order, which is all of
+// them when found <= annK, and the final order comes from (l2, id).  With set_only the kernel then
+// writes the heap array as it stands (same ids, same distances, heap order) and skips the sort;
+// as soon as the list would be truncated (found > k, results cap) it sorts as the reference does.
 struct TraverseArgs {
 	DevIndexView ix;
 	const int8_t *q;      // nq x dim packed
 	int nq, k, ef, cand_cap, results_cap;
+	int set_only;         // 1: the caller only needs the SET of candidates (see traverse_emit_unsorted)
 	uint32_t *visited;    // nq x vis_words, zeroed by the launcher
 	size_t vis_words;
 	int32_t *out_ids;     // nq x k
@@ -489,7 +496,10 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 	found = res_size;
 	rpipe.drain();
 	cpipe.drain();
-	for (int i = 0; i < found; i++) {
+	const bool unsorted = a.set_only && found <= a.k && found <= a.results_cap && found <= MVDB_MAX_EF;
+	if (unsorted)
+		for (int i = lane; i < found; i += 64) cand_h[i] = res_h[1 + i];
+	for (int i = 0; i < (unsorted ? 0 : found); i++) {
 		const int last = found - i;  // slot of the entry this pop carries to the root
 		rpipe.tick();                // the previous pop leaves level 2
 		while (rpipe.on_chain_to(last)) rpipe.tick();

@@ -554,7 +554,11 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 	// The candidate heap is dead now (the access wave has left); its arrays stage the output.
 	const int found = res_size;
 	rpipe.drain();
-	for (int i = 0; i < found; i++) {
+	// set_only (see TraverseArgs): nothing is cut off, the caller needs the set -> heap order, no sort
+	const bool unsorted = a.set_only && found <= a.k && found <= a.results_cap && found <= MVDB_MAX_EF;
+	if (unsorted)
+		for (int i = lane; i < found; i += 64) cand_h[i] = res_h[1 + i];
+	for (int i = 0; i < (unsorted ? 0 : found); i++) {
 		const int last = found - i;
 		rpipe.tick();
 		while (rpipe.on_chain_to(last)) rpipe.tick();
