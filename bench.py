@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--build-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="batches in flight: 2 = batch i on stream i %% 2 (the next batch's workgroups fill the "
+                         "places of queries that finished early), 1 = one batch at a time")
     ap.add_argument("--pipeline", action="store_true",
                     help="batch i's rerank on a second stream under batch i+1's traversal (measured slower on "
                          "MI355X: 4.52 vs 4.34 ms per batch, DESIGN.md 4.1; default: one batch at a time)")
@@ -159,12 +162,16 @@ def main():
     id_offset = rank * N if sharded else 0
 
     pipelined = args.pipeline
+    interleaved = args.in_flight == 2 and not pipelined
     if pipelined:
         os.environ.setdefault("MVDB_RERANK_WAVES", "2")  # rerank workgroups that fit beside a running traversal
 
     def step():
-        if pipelined:
-            slot, ids, l2, n = searcher.submit(q_dev, ef_search, ann_k)
+        if pipelined or interleaved:
+            if pipelined:
+                slot, ids, l2, n = searcher.submit(q_dev, ef_search, ann_k)
+            else:  # q_dev is resident and never rewritten: no need to order the batch behind this stream
+                slot, ids, l2, n = searcher.submit_interleaved(q_dev, ef_search, ann_k, sync_with_current=False)
             if world == 1:
                 return ids, l2, n
             searcher.wait(slot)
@@ -175,15 +182,18 @@ def main():
         if sharded:
             gid = ids + id_offset if id_offset else ids
             all_ids, all_l2, all_n = gather_topk(gid, l2, n)          # the one exchange step (RCCL all-gather)
-            return searcher.merge_topk(all_ids, all_l2, all_n, world, nq)
-        # replicas: every rank ends up with every rank's answers
-        return gather_topk(ids, l2, n)
+            out = searcher.merge_topk(all_ids, all_l2, all_n, world, nq)
+        else:  # replicas: every rank ends up with every rank's answers
+            out = gather_topk(ids, l2, n)
+        if pipelined or interleaved:
+            searcher.release(slot)  # the collectives above are the last readers of this slot's outputs
+        return out
 
     # ---------------- warmup + timed region -----------------------------------------------------
     log(f"rank {rank}: warmup {args.warmup} steps (first step uploads the index)")
     for _ in range(args.warmup):
         step()
-    if pipelined:
+    if pipelined or interleaved:
         searcher.drain()
     torch.cuda.synchronize(dev)
     bridge._L.mvdb_enable_timing(bridge.handle, 1)
@@ -194,7 +204,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
-    if pipelined:
+    if pipelined or interleaved:
         searcher.drain()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -238,6 +248,8 @@ def main():
                     rerank_bytes_per_launch=int(b_rerank.sum()),
                     rerank_avg_launch_ms=round(rerank_ms_total / max(n_launch, 1), 4),
                     prep_avg_launch_ms=round(prep_ms_total / max(n_launch, 1), 4),
+                    # with two batches in flight launches overlap: bytes of all launches / wall time
+                    effective_gbs=round(float(b_ann.sum()) * args.steps / elapsed / 1e9, 2),
                     pipeline_gbs=round(float(b_ann.sum() + b_rerank.sum()) / (ms_per_step * 1e-3) / 1e9, 2))
 
     # ---------------- recall@10 vs exact float32 brute force (rank 0, own queries) --------------
@@ -245,7 +257,7 @@ def main():
     ids_dev, l2_dev, n_dev = searcher.query_many(q_dev, ef_search, ann_k)
     torch.cuda.synchronize(dev)
     got = ids_dev.cpu().numpy()
-    if pipelined and world == 1:  # the pipelined batches answered the same queries: same bits expected
+    if (pipelined or interleaved) and world == 1:  # the overlapped batches answered the same queries: same bits expected
         p_ids, p_l2, p_n = last
         assert torch.equal(p_ids, ids_dev) and torch.equal(p_l2, l2_dev) and torch.equal(p_n, n_dev), \
             "pipelined and single-stream results differ"
@@ -305,7 +317,8 @@ def main():
                                n=N, dim=dim, nq=nq, topk=tk, ann_k=ann_k, preset=args.preset,
                                mode=("single" if world == 1 else args.mode),
                                batches=("pipelined: rerank of batch i on a second stream under the traversal "
-                                        "of batch i+1" if pipelined else "one at a time"),
+                                        "of batch i+1" if pipelined else
+                                        "two in flight: batch i on stream i % 2" if interleaved else "one at a time"),
                                graph="engine parallel builder (reference insert algorithm, unordered)"),
                    recall_at_10=None if recall is None else round(recall, 4),
                    roofline=roofline, cpu_baseline=cpu_baseline,

@@ -196,7 +196,16 @@ struct mvdb_index {
 	int64_t f32_rows = 0;
 
 	// scratch
-	DevBuf visited, st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
+	// Per-stream scratch (two streams at most): visited bitmaps and the intermediates of the fused
+	// query path, so that two batches on different streams can be in flight together; launches on
+	// one stream are ordered anyway.  A third stream takes over the older set once its stream drained.
+	struct StreamScratch {
+		hipStream_t stream = nullptr;
+		bool used = false;
+		DevBuf visited, qf, q8, ids, dist, cnt;
+	} ss[2];
+	int ss_lru = 0;
+	DevBuf st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
 		st_misc, scan_part, prof_buf;
 
 	bool timing = false;
@@ -517,6 +526,30 @@ int mvdb_prepare_queries(mvdb_index *h, const float *q_in, int nq, float *q_norm
 }  // extern "C"
 
 namespace {
+mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
+{
+	for (auto &c : h->ss)
+		if (c.used && c.stream == s) {
+			h->ss_lru = (&c == &h->ss[0]) ? 1 : 0;
+			return &c;
+		}
+	for (auto &c : h->ss)
+		if (!c.used) {
+			c.used = true;
+			c.stream = s;
+			h->ss_lru = (&c == &h->ss[0]) ? 1 : 0;
+			return &c;
+		}
+	mvdb_index::StreamScratch &c = h->ss[h->ss_lru];
+	if (hipStreamSynchronize(c.stream) != hipSuccess) {
+		h->set_error("hipStreamSynchronize failed while re-assigning per-stream scratch");
+		return nullptr;
+	}
+	c.stream = s;
+	h->ss_lru ^= 1;
+	return &c;
+}
+
 // shared by mvdb_search_many_dev (sorted lists, the bridge contract) and the fused query path
 // (set_only: see TraverseArgs)
 int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids, float *d_out_dist,
@@ -553,7 +586,9 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	// visited bitmaps: bounded scratch, queries are processed in slabs
 	const size_t slab_bytes_max = (size_t)2 << 30;
 	int slab = (int)std::min<size_t>((size_t)nq, std::max<size_t>(1, slab_bytes_max / (a.vis_words * 4)));
-	uint32_t *vis = static_cast<uint32_t *>(h->visited.need((size_t)slab * a.vis_words * 4));
+	mvdb_index::StreamScratch *sc = scratch_for(h, s);
+	if (!sc) return 0;
+	uint32_t *vis = static_cast<uint32_t *>(sc->visited.need((size_t)slab * a.vis_words * 4));
 	if (!vis) {
 		h->set_error("out of device memory (visited bitmaps)");
 		return 0;
@@ -765,11 +800,13 @@ int mvdb_query_many_dev(mvdb_index *h, const float *d_q_f32, int nq, int topk, i
 	mvdb_ensure_results_cap_at_least(h, ann_k);       // :577
 	const size_t nqd = (size_t)nq * h->cfg.dim;
 	const int ak = std::max(ann_k, 1);
-	float *d_qf = static_cast<float *>(h->st_qf.need(nqd * 4));
-	int8_t *d_q8 = static_cast<int8_t *>(h->st_q8.need(nqd));
-	int32_t *d_ids = static_cast<int32_t *>(h->st_ids.need((size_t)nq * ak * 4));
-	float *d_dist = static_cast<float *>(h->st_dist.need((size_t)nq * ak * 4));
-	int32_t *d_cnt = static_cast<int32_t *>(h->st_cnt.need((size_t)nq * 4));
+	mvdb_index::StreamScratch *sc = scratch_for(h, static_cast<hipStream_t>(stream));
+	if (!sc) return 0;
+	float *d_qf = static_cast<float *>(sc->qf.need(nqd * 4));
+	int8_t *d_q8 = static_cast<int8_t *>(sc->q8.need(nqd));
+	int32_t *d_ids = static_cast<int32_t *>(sc->ids.need((size_t)nq * ak * 4));
+	float *d_dist = static_cast<float *>(sc->dist.need((size_t)nq * ak * 4));
+	int32_t *d_cnt = static_cast<int32_t *>(sc->cnt.need((size_t)nq * 4));
 	if (!d_qf || !d_q8 || !d_ids || !d_dist || !d_cnt) {
 		h->set_error("out of device memory (query pipeline scratch)");
 		return 0;

@@ -67,7 +67,8 @@ class ResidentSearcher:
                 ids=torch.empty((nq, self.topk), dtype=torch.int32, device=dev),
                 l2=torch.empty((nq, self.topk), dtype=torch.float64, device=dev),
                 n=torch.empty((nq,), dtype=torch.int32, device=dev),
-                ready=torch.cuda.Event(), done=torch.cuda.Event(), used=False))
+                ready=torch.cuda.Event(), done=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False,
+                has_consumer=False))
 
     def submit(self, q_f32: torch.Tensor, ef_search: int, ann_k: int, allow: torch.Tensor | None = None):
         """Enqueue one batch; returns (slot, ids, l2, n) -- tensors are valid after wait(slot)."""
@@ -103,9 +104,51 @@ class ResidentSearcher:
         self.ctr = s["ctr"]
         return slot, s["ids"], s["l2"], s["n"]
 
+    def submit_interleaved(self, q_f32: torch.Tensor, ef_search: int, ann_k: int, allow: torch.Tensor | None = None,
+                           sync_with_current: bool = True):
+        """Two whole batches in flight: batch i runs prep -> traversal -> rerank on stream i % 2.
+        A traversal's queries finish at different times (the slowest takes ~20 % longer than the
+        mean) and a 1 k-query batch does not fill the LDS of the chip; the next batch's workgroups take
+        the places as they come free.  Same return convention as submit().  `sync_with_current=False`
+        when the queries were not produced on the caller's current stream (resident query sets):
+        otherwise the batch also waits for whatever else that stream has queued, e.g. the
+        all-gather of the previous batch."""
+        assert q_f32.is_cuda and q_f32.dtype == torch.float32 and q_f32.is_contiguous()
+        nq, dim = q_f32.shape
+        self._pipe_init(nq, dim, int(ann_k))
+        slot = self._pipe_i & 1
+        self._pipe_i += 1
+        s = self._slots[slot]
+        L, h = self.L, self.h
+        L.mvdb_set_ef_search(h, int(ef_search))
+        L.mvdb_ensure_results_cap_at_least(h, int(ann_k))
+        cur = torch.cuda.current_stream(self.device)
+        S = self._t_stream if slot == 0 else self._r_stream   # stream order protects the slot's buffers
+        if sync_with_current:
+            S.wait_stream(cur)
+        elif s["has_consumer"]:
+            S.wait_event(s["consumed"])  # whoever read this slot's outputs two batches ago (release())
+        vp = C.c_void_p
+        # the engine keeps one set of intermediates (and visited bitmaps) per stream, two streams at most
+        self.b._check(L.mvdb_query_many_dev(h, vp(q_f32.data_ptr()), nq, self.topk, int(ef_search), int(ann_k),
+                                            vp(allow.data_ptr()) if allow is not None else None,
+                                            vp(s["ids"].data_ptr()), vp(s["l2"].data_ptr()), vp(s["n"].data_ptr()),
+                                            vp(s["ctr"].data_ptr()), vp(S.cuda_stream)))
+        s["done"].record(S)
+        s["used"] = True
+        self.ctr = s["ctr"]
+        return slot, s["ids"], s["l2"], s["n"]
+
     def wait(self, slot: int):
         """Make the caller's current stream wait for the batch in `slot`."""
         torch.cuda.current_stream(self.device).wait_event(self._slots[slot]["done"])
+
+    def release(self, slot: int):
+        """Tell the pipeline that everything queued so far on the caller's current stream has finished
+        with the outputs of `slot` (needed with sync_with_current=False when another stream reads them)."""
+        s = self._slots[slot]
+        s["consumed"].record(torch.cuda.current_stream(self.device))
+        s["has_consumer"] = True
 
     def drain(self):
         cur = torch.cuda.current_stream(self.device)
