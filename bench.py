@@ -79,9 +79,9 @@ def main():
     ap.add_argument("--build-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
-                    help="batches in flight: 2 = batch i on stream i %% 2 (the next batch's workgroups fill the "
-                         "places of queries that finished early), 1 = one batch at a time")
+    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="batches in flight: batch i runs on stream i %% IN_FLIGHT (the next batches' workgroups "
+                         "fill the places of queries that finished early); 1 = one batch at a time")
     ap.add_argument("--pipeline", action="store_true",
                     help="batch i's rerank on a second stream under batch i+1's traversal (measured slower on "
                          "MI355X: 4.52 vs 4.34 ms per batch, DESIGN.md 4.1; default: one batch at a time)")
@@ -162,7 +162,7 @@ def main():
     id_offset = rank * N if sharded else 0
 
     pipelined = args.pipeline
-    interleaved = args.in_flight == 2 and not pipelined
+    interleaved = args.in_flight >= 2 and not pipelined
     if pipelined:
         os.environ.setdefault("MVDB_RERANK_WAVES", "2")  # rerank workgroups that fit beside a running traversal
 
@@ -171,7 +171,8 @@ def main():
             if pipelined:
                 slot, ids, l2, n = searcher.submit(q_dev, ef_search, ann_k)
             else:  # q_dev is resident and never rewritten: no need to order the batch behind this stream
-                slot, ids, l2, n = searcher.submit_interleaved(q_dev, ef_search, ann_k, sync_with_current=False)
+                slot, ids, l2, n = searcher.submit_interleaved(q_dev, ef_search, ann_k, sync_with_current=False,
+                                                                   depth=args.in_flight)
             if world == 1:
                 return ids, l2, n
             searcher.wait(slot)
@@ -248,8 +249,10 @@ def main():
                     rerank_bytes_per_launch=int(b_rerank.sum()),
                     rerank_avg_launch_ms=round(rerank_ms_total / max(n_launch, 1), 4),
                     prep_avg_launch_ms=round(prep_ms_total / max(n_launch, 1), 4),
-                    # with two batches in flight launches overlap: bytes of all launches / wall time
+                    # launches overlap when several batches are in flight: `achieved` (per launch, by the
+                    # definition) then understates what the chip delivers; bytes of all timed launches / wall:
                     effective_gbs=round(float(b_ann.sum()) * args.steps / elapsed / 1e9, 2),
+                    effective_frac=round(float(b_ann.sum()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                     pipeline_gbs=round(float(b_ann.sum() + b_rerank.sum()) / (ms_per_step * 1e-3) / 1e9, 2))
 
     # ---------------- recall@10 vs exact float32 brute force (rank 0, own queries) --------------
@@ -318,7 +321,8 @@ def main():
                                mode=("single" if world == 1 else args.mode),
                                batches=("pipelined: rerank of batch i on a second stream under the traversal "
                                         "of batch i+1" if pipelined else
-                                        "two in flight: batch i on stream i % 2" if interleaved else "one at a time"),
+                                        f"{args.in_flight} in flight: batch i on stream i % {args.in_flight}" if interleaved
+                                        else "one at a time"),
                                graph="engine parallel builder (reference insert algorithm, unordered)"),
                    recall_at_10=None if recall is None else round(recall, 4),
                    roofline=roofline, cpu_baseline=cpu_baseline,

@@ -181,6 +181,8 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 }
 
 // --------------------------------------------------------------------------- handle
+constexpr int kStreamSets = 4;
+
 struct mvdb_index {
 	mvdb_config cfg{};
 	HostGraph g;
@@ -196,15 +198,15 @@ struct mvdb_index {
 	int64_t f32_rows = 0;
 
 	// scratch
-	// Per-stream scratch (two streams at most): visited bitmaps and the intermediates of the fused
-	// query path, so that two batches on different streams can be in flight together; launches on
-	// one stream are ordered anyway.  A third stream takes over the older set once its stream drained.
+	// Per-stream scratch (kStreamSets streams at most): visited bitmaps and the intermediates of the
+	// fused query path, so that batches on different streams can be in flight together; launches on
+	// one stream are ordered anyway.  One stream more takes over a set once that set's stream drained.
 	struct StreamScratch {
 		hipStream_t stream = nullptr;
 		bool used = false;
 		DevBuf visited, qf, q8, ids, dist, cnt;
-	} ss[2];
-	int ss_lru = 0;
+	} ss[kStreamSets];
+	int ss_next = 0;  // round-robin victim when every set is taken
 	DevBuf st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
 		st_misc, scan_part, prof_buf;
 
@@ -529,24 +531,20 @@ namespace {
 mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
 {
 	for (auto &c : h->ss)
-		if (c.used && c.stream == s) {
-			h->ss_lru = (&c == &h->ss[0]) ? 1 : 0;
-			return &c;
-		}
+		if (c.used && c.stream == s) return &c;
 	for (auto &c : h->ss)
 		if (!c.used) {
 			c.used = true;
 			c.stream = s;
-			h->ss_lru = (&c == &h->ss[0]) ? 1 : 0;
 			return &c;
 		}
-	mvdb_index::StreamScratch &c = h->ss[h->ss_lru];
+	mvdb_index::StreamScratch &c = h->ss[h->ss_next];
+	h->ss_next = (h->ss_next + 1) % kStreamSets;
 	if (hipStreamSynchronize(c.stream) != hipSuccess) {
 		h->set_error("hipStreamSynchronize failed while re-assigning per-stream scratch");
 		return nullptr;
 	}
 	c.stream = s;
-	h->ss_lru ^= 1;
 	return &c;
 }
 

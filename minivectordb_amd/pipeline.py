@@ -44,19 +44,24 @@ class ResidentSearcher:
     # batch i's rerank on a second stream, it runs under batch i+1's traversal (set
     # MVDB_RERANK_WAVES=2 so that a rerank workgroup fits beside four traversal workgroups on a
     # CU).  Results of a submitted batch are valid after `wait(slot)`/`drain()`.
-    def _pipe_init(self, nq: int, dim: int, ann_k: int):
-        key = (nq, dim, ann_k)
+    def _pipe_init(self, nq: int, dim: int, ann_k: int, depth: int = 2):
+        key = (nq, dim, ann_k, depth)
         if getattr(self, "_pipe_key", None) == key:
             return
         dev = self.device
+        if getattr(self, "_pipe_key", None) is not None:
+            torch.cuda.synchronize(dev)  # batches of the previous shape may still use the old buffers
         self._pipe_key = key
         self._pipe_i = 0
         # the traversal needs all its workgroups resident at once (it is latency-bound): its stream gets
         # the high priority so that a ready rerank never takes their place at dispatch
         self._t_stream = torch.cuda.Stream(device=dev, priority=-1)
         self._r_stream = torch.cuda.Stream(device=dev, priority=0)
+        # whole-batch streams of submit_interleaved (the engine keeps up to 4 per-stream scratch sets)
+        self._depth = depth
+        self._b_streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         self._slots = []
-        for _ in range(2):
+        for _ in range(max(2, depth)):
             self._slots.append(dict(
                 qf=torch.empty((nq, dim), dtype=torch.float32, device=dev),
                 q8=torch.empty((nq, dim), dtype=torch.int8, device=dev),
@@ -105,8 +110,8 @@ class ResidentSearcher:
         return slot, s["ids"], s["l2"], s["n"]
 
     def submit_interleaved(self, q_f32: torch.Tensor, ef_search: int, ann_k: int, allow: torch.Tensor | None = None,
-                           sync_with_current: bool = True):
-        """Two whole batches in flight: batch i runs prep -> traversal -> rerank on stream i % 2.
+                           sync_with_current: bool = True, depth: int = 2):
+        """`depth` (2..4) whole batches in flight: batch i runs prep -> traversal -> rerank on stream i % depth.
         A traversal's queries finish at different times (the slowest takes ~20 % longer than the
         mean) and a 1 k-query batch does not fill the LDS of the chip; the next batch's workgroups take
         the places as they come free.  Same return convention as submit().  `sync_with_current=False`
@@ -115,15 +120,16 @@ class ResidentSearcher:
         all-gather of the previous batch."""
         assert q_f32.is_cuda and q_f32.dtype == torch.float32 and q_f32.is_contiguous()
         nq, dim = q_f32.shape
-        self._pipe_init(nq, dim, int(ann_k))
-        slot = self._pipe_i & 1
+        assert 2 <= depth <= 4
+        self._pipe_init(nq, dim, int(ann_k), depth)
+        slot = self._pipe_i % depth
         self._pipe_i += 1
         s = self._slots[slot]
         L, h = self.L, self.h
         L.mvdb_set_ef_search(h, int(ef_search))
         L.mvdb_ensure_results_cap_at_least(h, int(ann_k))
         cur = torch.cuda.current_stream(self.device)
-        S = self._t_stream if slot == 0 else self._r_stream   # stream order protects the slot's buffers
+        S = self._b_streams[slot]   # stream order protects the slot's buffers
         if sync_with_current:
             S.wait_stream(cur)
         elif s["has_consumer"]:
@@ -154,6 +160,8 @@ class ResidentSearcher:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(self._t_stream)
         cur.wait_stream(self._r_stream)
+        for st in self._b_streams:
+            cur.wait_stream(st)
 
     def merge_topk(self, ids: torch.Tensor, l2: torch.Tensor, n: torch.Tensor, parts: int, nq: int):
         """Merge [parts][nq][topk] per-shard results by (l2, id)."""

@@ -218,9 +218,13 @@ def test_pipelined_batches_equal_single_stream(gpu):
     try:
         batches = [torch.from_numpy(gaussian_unit(200, 384, 100 + i)).to(dev) for i in range(5)]
         outs = []
-        for i, q in enumerate(batches + batches):
-            sub = s.submit if i < len(batches) else s.submit_interleaved  # both overlap modes
-            slot, ids, l2, n = sub(q, 140, 1200)
+        for i, q in enumerate(batches + batches + batches):
+            if i < len(batches):
+                slot, ids, l2, n = s.submit(q, 140, 1200)                      # rerank on a second stream
+            elif i < 2 * len(batches):
+                slot, ids, l2, n = s.submit_interleaved(q, 140, 1200)          # two whole batches in flight
+            else:
+                slot, ids, l2, n = s.submit_interleaved(q, 140, 1200, depth=4)  # four
             s.wait(slot)
             outs.append((ids.clone(), l2.clone(), n.clone()))  # on the current stream, after the wait
         s.drain()
@@ -230,7 +234,7 @@ def test_pipelined_batches_equal_single_stream(gpu):
             os.environ.pop("MVDB_RERANK_WAVES", None)
         else:
             os.environ["MVDB_RERANK_WAVES"] = old
-    for q, (ids, l2, n) in zip(batches + batches, outs):
+    for q, (ids, l2, n) in zip(batches + batches + batches, outs):
         r_ids, r_l2, r_n = s.query_many(q, 140, 1200)
         torch.cuda.synchronize(dev)
         assert torch.equal(ids, r_ids) and torch.equal(l2, r_l2) and torch.equal(n, r_n)
