@@ -46,6 +46,9 @@
 
 namespace mvdb {
 
+#ifndef MVDB_DUO_POLL_SLEEP
+#define MVDB_DUO_POLL_SLEEP 1  // s_sleep argument (x64 cycles) between two polls of a mailbox
+#endif
 #ifndef MVDB_DUO_POSTPOP_TICKS
 #define MVDB_DUO_POSTPOP_TICKS 0  // measured at 1M x 384, ef 1200: 0 -> 3.87 ms, 4 -> 3.98, 16 -> 4.16
 #endif
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 					dead = true;
 					break;
 				}
-				__builtin_amdgcn_s_sleep(1);
+				__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
 			}
 			MVDB_DUO_STAMP(2);
 			if (dead) break;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				dead = true;
 				break;
 			}
-			__builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
 		}
 		if (dead) break;
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 					dead = true;
 					break;
 				}
-				__builtin_amdgcn_s_sleep(1);
+				__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
 			}
 			if (dead) break;
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 		a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
 	}
 	for (int spin = 0; rfl(*reinterpret_cast<volatile int *>(&sy->fin)) == 0 && spin < kDuoSpinLimit; spin++)
-		__builtin_amdgcn_s_sleep(1);
+		__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	if (lane == 0) {
 		a.out_count[qi] = out_count;
