@@ -37,15 +37,26 @@
 // evaluate the termination test (:466) from the same values.  Every wait is bounded; a wave that
 // gives up raises `abort` and the query reports count -1.
 // Memory phase: the visited test-and-set and the row gather of ALL listed neighbours are issued
-// together (about nine in ten listed neighbours are new at ef ~ 1200, the rest is discarded),
-// the list of the root the pop leaves is fetched at pop time, and one dword of every listed
-// neighbour's own list is touched so that the next list is an L2 hit.
+// together (about nine in ten listed neighbours are new at ef ~ 1200, the rest is discarded;
+// measured 3-4 % faster than rows-after-visited).  Two more latency tricks are kept behind macros
+// and off: fetching the list of the root the pop leaves at pop time (MVDB_DUO_PREF) and touching
+// one dword of every listed neighbour's own list so that the next list is an L2 hit
+// (MVDB_DUO_WARM, +25 % HBM traffic) -- neither moved the batch time.
 #pragma once
 
 #include "traverse.hip.hpp"
 
 namespace mvdb {
 
+#ifndef MVDB_DUO_SPEC_ROWS
+#define MVDB_DUO_SPEC_ROWS 1  // gather the rows of every listed neighbour together with the visited test
+#endif
+#ifndef MVDB_DUO_WARM
+#define MVDB_DUO_WARM 0  // touch the listed neighbours' own lists (L2 warm-up for the next pop): +25 % HBM traffic, no gain measured
+#endif
+#ifndef MVDB_DUO_PREF
+#define MVDB_DUO_PREF 0  // fetch the list of the root the pop leaves at pop time: no gain measured
+#endif
 #ifndef MVDB_DUO_POLL_SLEEP
 #define MVDB_DUO_POLL_SLEEP 1  // s_sleep argument (x64 cycles) between two polls of a mailbox
 #endif
@@ -258,7 +269,19 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 			if (nb >= 0) {  // :494-495
 				bit = 1u << (nb & 31);
 				old = atomicOr(&vis[(unsigned)nb >> 5], bit);
-				all_ids[lane] = nb;
+				if (MVDB_DUO_SPEC_ROWS) all_ids[lane] = nb;
+			}
+			if (!MVDB_DUO_SPEC_ROWS) {
+				// rows of the NEW neighbours only, after the visited words are back
+				background(6);
+				const bool isnew = nb >= 0 && !(old & bit);
+				const unsigned long long nm = __ballot(isnew);
+				const int n = __builtin_popcountll(nm);
+				if (n == 0) return 0;
+				int *ids = ids_b + 64 * b;
+				if (isnew) ids[__builtin_popcountll(nm & ((1ull << lane) - 1))] = nb;
+				dist_rows<J, FULL>(ix, Q, ids, dist_b + 64 * b, n, c_id, lane);  // :497
+				return n;
 			}
 			const int g = lane >> 3, sl = lane & 7;
 			int warm = 0;
@@ -275,7 +298,7 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				}
 				if (first) {
 					// first dword of every listed neighbour's own list: the next pop's list becomes an L2 hit
-					if (nb >= 0) warm = ix.adj0[(size_t)nb * (size_t)ix.m0];
+					if (MVDB_DUO_WARM && nb >= 0) warm = ix.adj0[(size_t)nb * (size_t)ix.m0];
 					MVDB_DUO_STAMP(11);
 					background(12);
 					MVDB_DUO_STAMP(12);
@@ -379,9 +402,11 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				cpipe.tick();  // root step: the root is final
 				o_key = (unsigned)__builtin_amdgcn_readlane((int)cpipe.root_key, owner);
 				o_id = __builtin_amdgcn_readlane((int)cpipe.root_id, owner);
-				pref_id = o_id;  // its list is needed next unless a new neighbour undercuts it
-				pref_nb = -1;
-				if (lane < ix.m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)ix.m0 + lane];
+				if (MVDB_DUO_PREF) {
+					pref_id = o_id;  // its list is needed next unless a new neighbour undercuts it
+					pref_nb = -1;
+					if (lane < ix.m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)ix.m0 + lane];
+				}
 			}
 			sift_e = e;
 			sift_pub = false;
