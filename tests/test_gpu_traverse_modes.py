@@ -89,3 +89,33 @@ def test_heavy_ties(gpu):
     q8 = (np.random.default_rng(12).integers(-1, 2, (64, 16)) * 64).astype(np.int8)
     for k, ef in [(10, 10), (64, 64), (500, 500), (1200, 1200)]:
         _same(b, ix, q8, k, ef)
+
+
+def test_fused_query_path_set_only_output(gpu):
+    """mvdb_query_many lets the traversal skip its final heap sort when nothing is cut off (set_only).
+    Both kernels, with and without an allow bitmap, must return the oracle pipeline's bits; with
+    efSearch > annK the candidate list IS cut off (found > k) and the kernels must sort as the reference."""
+    from tests._data import bridge_from_dump, built_index, oracle_from_dump
+    dump, base, b8 = built_index(4000, 384, "balanced")
+    b = bridge_from_dump(dump, 384, "balanced")
+    ix = oracle_from_dump(dump, 384, "balanced")
+    b.attachF32(base)
+    rng = np.random.default_rng(77)
+    q = rng.standard_normal((60, 384)).astype(np.float32)
+    allow = rng.integers(0, 2**32, (4000 + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    qf = O.normalize_rows_f32(q)
+    qi = O.quantize_rows_i8(qf)
+    for ef, ann_k, bitmap in [(1200, 1200, None), (1200, 1200, allow), (300, 120, None), (300, 120, allow), (50, 400, None)]:
+        ix.set_ef_search(ef)
+        ix.set_results_cap(4096)
+        ids, dist, cnt, _ = ix.search_many(qi, ann_k, threads=8)
+        oi, ol, on = O.rerank_many(qf, base, ids, cnt, ann_k, 10, bitmap, 8)
+        for waves in ("1", "2"):
+            os.environ["MVDB_TRAVERSE_WAVES"] = waves
+            try:
+                gi, gl, gn = b.queryMany(q, 10, ef, ann_k, allow_bitmap=bitmap)
+            finally:
+                os.environ.pop("MVDB_TRAVERSE_WAVES", None)
+            assert np.array_equal(gn, on), (waves, ef, ann_k)
+            assert np.array_equal(gi, oi), (waves, ef, ann_k)
+            assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64)), (waves, ef, ann_k)
