@@ -163,8 +163,9 @@ def main():
 
     pipelined = args.pipeline
     interleaved = args.in_flight >= 2 and not pipelined
-    if pipelined:
-        os.environ.setdefault("MVDB_RERANK_WAVES", "2")  # rerank workgroups that fit beside a running traversal
+    if pipelined or interleaved:
+        # 2-wave rerank workgroups (34 KB of LDS) find room beside running traversals: +2 % with 3 in flight
+        os.environ.setdefault("MVDB_RERANK_WAVES", "2")
 
     def step():
         if pipelined or interleaved:
