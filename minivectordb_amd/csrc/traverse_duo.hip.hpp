@@ -528,7 +528,9 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				adm_mask |= 1ull << t;
 				if (res_size < ef) {
 					res.push(res_size++, nid, d, lane);  // :504-505
-					worst = (unsigned)rfl((int)res_h[1].x);
+					// `worst` is only consulted once the heap is full (:466, :499): one LDS round trip
+					// per neighbour saved while it fills
+					if (res_size >= ef) worst = (unsigned)rfl((int)res_h[1].x);
 				} else {
 					rpipe.tick();  // :506-507 replace_root, pipelined (see traverse_kernel)
 					const int owner = rpipe.issue(lane, res_size, d, (unsigned)nid);
