@@ -320,23 +320,34 @@ int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStrea
 	return 1;
 }
 
+template <int J, bool FULL, int WAVES>
+int launch_traverse_duo_w(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
+{
+	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&traverse_duo_kernel<J, FULL, WAVES>),
+	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((traverse_duo_kernel<J, FULL, WAVES>), dim3(a.nq), dim3(64 * WAVES), lds, s, a);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+int traverse_waves_forced()
+{
+	const char *e = std::getenv("MVDB_TRAVERSE_WAVES");
+	return e ? std::atoi(e) : 0;
+}
+
 template <int J, bool FULL>
 int launch_traverse_duo_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
 {
-	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&traverse_duo_kernel<J, FULL>),
-	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL((traverse_duo_kernel<J, FULL>), dim3(a.nq), dim3(kDuoThreads), lds, s, a);
-	HIP_OK(h, hipGetLastError());
-	return 1;
+	if (traverse_waves_forced() == 3) return launch_traverse_duo_w<J, FULL, 3>(h, a, lds, s);
+	return launch_traverse_duo_w<J, FULL, 2>(h, a, lds, s);
 }
 
 // Two waves per query (traverse_duo.hip.hpp) whenever a neighbour list fits one 64-lane chunk;
 // MVDB_TRAVERSE_WAVES=1 selects the one-wave kernel for A/B timing.
 bool traverse_use_duo(const TraverseArgs &a)
 {
-	const char *e = std::getenv("MVDB_TRAVERSE_WAVES");
-	const int forced = e ? std::atoi(e) : 0;
-	return a.ix.m0 <= kDuoMaxM0 && forced != 1;
+	return a.ix.m0 <= kDuoMaxM0 && traverse_waves_forced() != 1;
 }
 
 int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)

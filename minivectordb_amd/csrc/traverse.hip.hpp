@@ -84,9 +84,14 @@ struct LdsHeap {
 	// place (nid, nkey) at the root of a heap of `size` and sift down (:191-210, :268-287)
 	__device__ __forceinline__ void sift_root(int size, int nid, unsigned nkey, int lane) const
 	{
+		sift_from(1, size, nid, nkey, lane);
+	}
+	// the same walk entered at slot p (a sift-down another wave started and handed over)
+	__device__ __forceinline__ void sift_from(int p, int size, int nid, unsigned nkey, int lane) const
+	{
 		size = rfl(size);  // keep the whole walk on the scalar unit
 		nkey = (unsigned)rfl((int)nkey);
-		int p = 1;
+		p = rfl(p);
 		for (;;) {
 			const int l = 2 * p;
 			if (l > size) break;

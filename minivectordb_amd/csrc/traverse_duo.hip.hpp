@@ -71,7 +71,9 @@ enum : int { kRecInit = 0, kRecList = 1, kRecEnd = 2 };
 
 struct DuoSync {
 	u32x4_t record[2];  // access wave -> result wave, by record parity
-	u32x4_t channel;    // result wave -> access wave
+	u32x4_t channel;    // result wave (two waves) / push wave (three waves) -> access wave
+	u32x4_t adm[2];     // three waves only: result wave -> push wave, by record parity
+	u32x4_t sift_req;   // three waves only: access wave -> push wave, {pop e, 8 * slot to go on from, key, id}
 	int sift_done;      // access wave -> result wave
 	int fin;            // access wave: counters below are final
 	int abort;
@@ -128,9 +130,11 @@ __host__ __device__ inline size_t traverse_duo_lds_bytes(int ef, int cand_cap)
 	} while (0)
 #endif
 
-template <int J, bool FULL>
-__global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs a)
+template <int J, bool FULL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a)
 {
+	static_assert(WAVES == 2 || WAVES == 3, "two or three waves per query");
+	constexpr bool TRIO = WAVES == 3;
 #ifdef MVDB_TRAVERSE_PROFILE
 	unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
@@ -161,13 +165,20 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 			sy->record[0] = u32x4_t{0, 0, 0, 0};
 			sy->record[1] = u32x4_t{0, 0, 0, 0};
 			sy->sift_done = 0;
+			sy->sift_req = u32x4_t{0, 0, 0, 0};
 			sy->fin = 0;
 			sy->abort = 0;
+		}
+	} else if (wave == 1) {
+		if (lane == 0) {
+			sy->adm[0] = u32x4_t{0, 0, 0, 0};
+			sy->adm[1] = u32x4_t{0, 0, 0, 0};
+			if (!TRIO) sy->channel = u32x4_t{0, 0, 0, 0};
 		}
 	} else {
 		if (lane == 0) sy->channel = u32x4_t{0, 0, 0, 0};
 	}
-	__syncthreads();  // the only barrier: both waves reach it unconditionally
+	__syncthreads();  // the only barrier: every wave reaches it unconditionally
 
 	if (wave == 0) {
 		// =========================== access wave ===========================
@@ -402,14 +413,21 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				cpipe.tick();  // root step: the root is final
 				o_key = (unsigned)__builtin_amdgcn_readlane((int)cpipe.root_key, owner);
 				o_id = __builtin_amdgcn_readlane((int)cpipe.root_id, owner);
+				if (TRIO) {
+					// the push wave walks the rest of the sift-down (it pushes right after it anyway)
+					const unsigned rest = (unsigned)__builtin_amdgcn_readlane((int)cpipe.a, owner);
+					cpipe.a = 0;
+					duo_publish(&sy->sift_req, u32x4_t{(unsigned)e, rest, last.x, last.y}, lane);
+				}
 				if (MVDB_DUO_PREF) {
 					pref_id = o_id;  // its list is needed next unless a new neighbour undercuts it
 					pref_nb = -1;
 					if (lane < ix.m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)ix.m0 + lane];
 				}
 			}
+			if (TRIO && cand_size == 0) duo_publish(&sy->sift_req, u32x4_t{(unsigned)e, 0u, 0u, 0u}, lane);
 			sift_e = e;
-			sift_pub = false;
+			sift_pub = TRIO;  // two waves: sift_done is posted once the pipe has drained
 			background(MVDB_DUO_POSTPOP_TICKS);  // part of the sift-down under the latency of the list fetch
 			n_l0++;
 			n_dist += n;
@@ -482,13 +500,95 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 		return;
 	}
 
+	if (TRIO && wave == 2) {
+		// =========================== push wave (three waves per query) ===========================
+		// Finishes the sift-down of pop e (the access wave takes the root step and hands the rest over)
+		// and replays the admitted neighbours of each list into the candidate heap (:500-502) WHILE the
+		// result wave is still admitting that list: the result wave posts the admitted-lane mask
+		// after every admission (adm[e & 1] = {mask, ((e + 1) << 8) | kind << 1 | done, worst}); bits
+		// only ever appear above the ones already set, so pushing the new bits of each snapshot in
+		// ascending order is the list order.  The channel to the access wave is posted from here.
+		int cand_size = 1;  // the access wave pushed the entry point (:453)
+		bool dead = false;
+		for (int e = 0; !dead; e++) {
+			unsigned long long pushed = 0;
+			bool popped = false, loaded = false;
+			unsigned my_d = 0;
+			int my_id = -1, kind = kRecList;
+			u32x4_t msg;
+			for (int spin = 0;;) {
+				msg = duo_snapshot(&sy->adm[e & 1]);
+				if ((int)(msg.z >> 8) == e + 1) {
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					kind = (int)((msg.z >> 1) & 3u);
+					const unsigned long long mask = (unsigned long long)msg.x | ((unsigned long long)msg.y << 32);
+					unsigned long long fresh = mask & ~pushed;
+					if (kind == kRecList && !popped) {
+						// pop e: the access wave took the root step, the rest of the sift-down is walked here
+						u32x4_t rq;
+						for (int sp2 = 0;;) {
+							rq = duo_snapshot(&sy->sift_req);
+							if ((int)rq.x == e) break;
+							if (++sp2 > kDuoSpinLimit || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+								dead = true;
+								break;
+							}
+							__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
+						}
+						if (dead) break;
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+						cand_size--;
+						popped = true;
+						if (rq.y != 0u) cand.sift_from((int)(rq.y >> 3), cand_size, (int)rq.w, rq.z, lane);
+					}
+					if (fresh) {
+						if (!loaded) {
+							my_d = dist_b[64 * (e & 1) + lane];
+							my_id = ids_b[64 * (e & 1) + lane];
+							loaded = true;
+						}
+						for (; fresh && cand_size < cand_cap; fresh &= fresh - 1) {
+							const int t = __builtin_ctzll(fresh);
+							cand.push(cand_size++, __builtin_amdgcn_readlane(my_id, t),
+							          (unsigned)__builtin_amdgcn_readlane((int)my_d, t), lane);
+						}
+						pushed = mask;
+						spin = 0;
+					}
+					if (msg.z & 1u) break;  // the record is complete
+					if (mask != pushed) continue;
+				}
+				if (++spin > kDuoSpinLimit || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+					dead = true;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
+			}
+			if (dead) break;
+			if (kind == kRecEnd) return;
+			duo_publish(&sy->channel, u32x4_t{msg.x, msg.y, (unsigned)(2 * e + 1), msg.w}, lane);
+		}
+		if (lane == 0) *reinterpret_cast<volatile int *>(&sy->abort) = 1;
+		return;
+	}
+
 	// =========================== result wave ===========================
 	int res_size = 0, cand_size = 1;  // the access wave pushed the entry point (:453)
 	unsigned worst = 0;
 	bool dead = false;
+	// three waves: message to the push wave.  No release fence: the push wave reads nothing this wave
+	// wrote but the message itself (the distances come from the access wave, seen through the record).
+	auto post_adm = [&](int e, unsigned long long mask, int kind, bool done, unsigned w) {
+		if (lane == 0)
+			*reinterpret_cast<volatile lds_u32x4 *>((size_t)(unsigned)(size_t)&sy->adm[e & 1]) =
+			    u32x4_t{(unsigned)mask, (unsigned)(mask >> 32),
+			            ((unsigned)(e + 1) << 8) | ((unsigned)kind << 1) | (done ? 1u : 0u), w};
+	};
+	int last_e = 0;  // record the loop was left on
 	HeapPipe<false> rpipe;
 	rpipe.base = (unsigned)(size_t)res_h;
 	for (int e = 0;; e++) {
+		last_e = e;
 		u32x4_t rec;
 		for (int spin = 0;;) {
 			rec = duo_snapshot(&sy->record[e & 1]);
@@ -526,6 +626,7 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				prof_admitted++;
 #endif
 				adm_mask |= 1ull << t;
+				if (TRIO) post_adm(e, adm_mask, kRecList, false, 0u);  // the push wave can start on it
 				if (res_size < ef) {
 					res.push(res_size++, nid, d, lane);  // :504-505
 					// `worst` is only consulted once the heap is full (:466, :499): one LDS round trip
@@ -539,6 +640,10 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 				}
 			}
 			MVDB_DUO_STAMP(6);
+			if (TRIO) {
+				post_adm(e, adm_mask, kRecList, true, worst);
+				continue;
+			}
 			// :500-502 for the admitted neighbours, in list order, once pop e has left the heap
 			for (int spin = 0;;) {
 				if (rfl(*reinterpret_cast<volatile int *>(&sy->sift_done)) >= e) break;
@@ -558,7 +663,24 @@ __global__ __launch_bounds__(kDuoThreads) void traverse_duo_kernel(TraverseArgs 
 			}
 			MVDB_DUO_STAMP(15);
 		}
-		duo_publish(&sy->channel, u32x4_t{(unsigned)adm_mask, (unsigned)(adm_mask >> 32), (unsigned)(2 * e + 1), worst}, lane);
+		if (TRIO) post_adm(e, 0ull, kRecInit, true, worst);
+		else
+			duo_publish(&sy->channel, u32x4_t{(unsigned)adm_mask, (unsigned)(adm_mask >> 32), (unsigned)(2 * e + 1), worst}, lane);
+	}
+	if (TRIO && !dead) {
+		// the push wave leaves; the candidate heap's arrays are reused below, so its last pushes
+		// (record last_e - 1) must have landed
+		post_adm(last_e, 0ull, kRecEnd, true, 0u);
+		for (int spin = 0; last_e > 0;) {
+			const u32x4_t ch = duo_snapshot(&sy->channel);
+			if ((int)ch.z == 2 * (last_e - 1) + 1) break;
+			if (++spin > kDuoSpinLimit || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
+				dead = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	}
 	if (dead || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
 		if (lane == 0) {

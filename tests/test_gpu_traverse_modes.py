@@ -40,7 +40,7 @@ def _same(b, ix, q8, k, ef):
     ix.set_ef_search(ef)
     oi, od, oc, octr = ix.search_many(q8, k, threads=8)
     outs = {}
-    for waves in ("1", "2"):
+    for waves in ("1", "2", "3"):
         os.environ["MVDB_TRAVERSE_WAVES"] = waves
         try:
             ids, dist, cnt, ctr = b.searchManyArrays(q8, k, with_counters=True)
@@ -110,7 +110,7 @@ def test_fused_query_path_set_only_output(gpu):
         ix.set_results_cap(4096)
         ids, dist, cnt, _ = ix.search_many(qi, ann_k, threads=8)
         oi, ol, on = O.rerank_many(qf, base, ids, cnt, ann_k, 10, bitmap, 8)
-        for waves in ("1", "2"):
+        for waves in ("1", "2", "3"):
             os.environ["MVDB_TRAVERSE_WAVES"] = waves
             try:
                 gi, gl, gn = b.queryMany(q, 10, ef, ann_k, allow_bitmap=bitmap)

@@ -63,7 +63,7 @@ def main():
 
     out = {"rows": rows, "dim": dim, "nq": nq, "ef": ef, "build_s": round(build_s, 1)}
     results = {}
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         os.environ["MVDB_TRAVERSE_WAVES"] = mode
         for _ in range(2):
             r = b.searchManyArrays(q8, ef, with_counters=True)
@@ -73,7 +73,8 @@ def main():
         n1, t1 = stats(1)
         results[mode] = r
         out[f"waves{mode}_ms"] = t1 / max(n1, 1)
-    same = all(np.array_equal(x, y) for x, y in zip(results["1"], results["2"]))
+    same = all(np.array_equal(x, y) for x, y in zip(results["1"], results["2"])) and all(
+        np.array_equal(x, y) for x, y in zip(results["1"], results["3"]))
     out["identical"] = bool(same)
     out["mean_n_dist"] = float(results["2"][3][:, 0].mean())
     out["mean_l0lists"] = float(results["2"][3][:, 1].mean())
