@@ -339,12 +339,13 @@ int traverse_waves_forced()
 template <int J, bool FULL>
 int launch_traverse_duo_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
 {
-	if (traverse_waves_forced() == 3) return launch_traverse_duo_w<J, FULL, 3>(h, a, lds, s);
-	return launch_traverse_duo_w<J, FULL, 2>(h, a, lds, s);
+	if (traverse_waves_forced() == 2) return launch_traverse_duo_w<J, FULL, 2>(h, a, lds, s);
+	return launch_traverse_duo_w<J, FULL, 3>(h, a, lds, s);
 }
 
-// Two waves per query (traverse_duo.hip.hpp) whenever a neighbour list fits one 64-lane chunk;
-// MVDB_TRAVERSE_WAVES=1 selects the one-wave kernel for A/B timing.
+// Several waves per query (traverse_duo.hip.hpp: three by default, MVDB_TRAVERSE_WAVES=2 for the
+// two-wave variant) whenever a neighbour list fits one 64-lane chunk; MVDB_TRAVERSE_WAVES=1
+// selects the one-wave kernel for A/B timing.
 bool traverse_use_duo(const TraverseArgs &a)
 {
 	return a.ix.m0 <= kDuoMaxM0 && traverse_waves_forced() != 1;
@@ -615,7 +616,7 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		a.ctr = d_ctr ? d_ctr + q0 : nullptr;
 		a.prof = nullptr;
 #ifdef MVDB_TRAVERSE_PROFILE
-		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 128)) + (size_t)q0 * 16;
+		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 192)) + (size_t)q0 * 24;
 #endif
 		if (!launch_traverse(h, a, s)) return 0;
 	}
@@ -1015,7 +1016,7 @@ int mvdb_debug_scan_counters(mvdb_index *h, unsigned long long *out)
 int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 {
 	if (!h->prof_buf.p) return 0;
-	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 128, hipMemcpyDeviceToHost) == hipSuccess;
+	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 192, hipMemcpyDeviceToHost) == hipSuccess;
 }
 #endif
 void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }

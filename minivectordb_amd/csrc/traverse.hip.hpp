@@ -108,6 +108,44 @@ struct LdsHeap {
 		}
 		if (lane == 0) h[p] = make_uint2(nkey, (unsigned)nid);
 	}
+	// The same walk, five levels per LDS round trip instead of one: lane j reads node j + 2 of the
+	// subtree under p in heap numbering (children 2, 3; grandchildren 4..7; ... 32..63), every node
+	// decides locally whether it is the child its parent would pick (:201 the right one only if
+	// strictly better) and whether the walk would go on through it (:206), and the path is then
+	// followed on the scalar unit through the ballot.  Entries on the path move up together.
+	__device__ __forceinline__ void sift_from_wide(int p, int size, int nid, unsigned nkey, int lane) const
+	{
+		static_assert(MIN, "written for the candidate min-heap (absent nodes read as +inf)");
+		size = rfl(size);
+		nkey = (unsigned)rfl((int)nkey);
+		p = rfl(p);
+		const int li = lane + 2;
+		const int d = 31 - __builtin_clz(li);  // 1..5 (6 in the two spare lanes)
+		const int off = li - (1 << d);
+		for (;;) {
+			if (2 * p > size) break;  // a leaf
+			const int pos = (p << d) + off;
+			const bool valid = lane < 62 && pos <= size;
+			u32x2_t en = *reinterpret_cast<const lds_u32x2 *>((size_t)(lds_base + (valid ? (unsigned)pos * 8u : 0u)));
+			en.x = valid ? en.x : 0xffffffffu;  // never below a key: f32 bit patterns of finite values
+			const unsigned ks = (unsigned)__builtin_amdgcn_update_dpp(0, (int)en.x, 0xB1, 0xf, 0xf, false);  // sibling
+			const bool chosen = (lane & 1) ? en.x < ks : en.x <= ks;
+			const unsigned long long cont = __ballot(chosen && nkey > en.x);
+			unsigned long long path = 0;
+			int cur = 1, steps = 0;
+			for (; steps < 5; steps++) {
+				const unsigned pair = (unsigned)(cont >> (2 * cur - 2)) & 3u;  // at most one bit: one child is chosen
+				if (!pair) break;
+				cur = 2 * cur + (int)(pair >> 1);
+				path |= 1ull << (cur - 2);
+			}
+			if ((path >> lane) & 1ull) *reinterpret_cast<lds_u32x2 *>((size_t)(lds_base + (unsigned)(pos >> 1) * 8u)) = en;
+			const int dc = 31 - __builtin_clz(cur);
+			p = (p << dc) + (cur - (1 << dc));
+			if (steps < 5) break;
+		}
+		if (lane == 0) h[p] = make_uint2(nkey, (unsigned)nid);
+	}
 	// pop the root; returns new size.  (rid, rkey) = old root.
 	__device__ __forceinline__ int pop(int size, int &rid, unsigned &rkey, int lane) const
 	{
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 #ifdef MVDB_TRAVERSE_PROFILE
 	MVDB_STAMP(6);  // output
 	if (lane == 0 && a.prof)
-		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * 16 + i] = prof_acc[i];
+		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * 24 + i] = prof_acc[i];
 #endif
 	if (lane == 0) {
 		a.out_count[qi] = out_count;

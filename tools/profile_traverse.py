@@ -33,7 +33,7 @@ if __name__ == "__main__":
     b.setEfSearch(ef)
     for _ in range(3):
         t0 = time.perf_counter(); ids, dist, cnt, ctr = b.searchManyArrays(qi8, ann_k, with_counters=True); t1 = time.perf_counter()
-    prof = np.zeros((nq, 16), np.uint64)
+    prof = np.zeros((nq, 24), np.uint64)
     L = b._L
     L.mvdb_debug_traverse_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     assert L.mvdb_debug_traverse_profile(b.handle, prof.ctypes.data_as(C.c_void_p), nq)
@@ -50,6 +50,8 @@ if __name__ == "__main__":
         acc = ["descent", "early_mem", "wait_adm+replay", "late_mem", "pop+publish+predict"]
         resw = ["wait_record", "admission", "final_sort"]
         print(f"  R cand pushes + wait sift {prof[:, 15].mean():12.0f} cyc")
+        for i, nm in zip(range(16, 20), ["wait message", "wait sift_req", "sift-down", "pushes"]):
+            print(f"  P {nm:20s} {prof[:, i].mean():12.0f} cyc")
         for i, nm in zip(range(10, 15), ["mem:list", "mem:issue", "mem:background", "mem:rows+dist", "mem:compact"]):
             print(f"  A {nm:20s} {prof[:, i].mean():12.0f} cyc")
         ta = prof[:, :5].sum(1).astype(np.float64) + prof[:, 10:15].sum(1).astype(np.float64)
