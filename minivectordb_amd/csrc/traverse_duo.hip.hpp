@@ -47,10 +47,11 @@
 // three batches in flight.
 // Memory phase: the visited test-and-set and the row gather of ALL listed neighbours are issued
 // together (about nine in ten listed neighbours are new at ef ~ 1200, the rest is discarded;
-// measured 3-4 % faster than rows-after-visited).  Two more latency tricks are kept behind macros
-// and off: fetching the list of the root the pop leaves at pop time (MVDB_DUO_PREF) and touching
-// one dword of every listed neighbour's own list so that the next list is an L2 hit
-// (MVDB_DUO_WARM, +25 % HBM traffic) -- neither moved the batch time.
+// measured 3-4 % faster than rows-after-visited).  The list of the root the pop leaves is fetched
+// at pop time (MVDB_DUO_PREF; it is the next candidate unless a new neighbour undercuts it; worth
+// 1-1.5 % once the third wave had shortened the other chains).  Touching one dword of every listed
+// neighbour's own list so that the next list is an L2 hit (MVDB_DUO_WARM, +25 % HBM traffic) is
+// kept behind its macro and off: it never moved the batch time.
 #pragma once
 
 #include "traverse.hip.hpp"
@@ -64,7 +65,7 @@ namespace mvdb {
 #define MVDB_DUO_WARM 0  // touch the listed neighbours' own lists (L2 warm-up for the next pop): +25 % HBM traffic, no gain measured
 #endif
 #ifndef MVDB_DUO_PREF
-#define MVDB_DUO_PREF 0  // fetch the list of the root the pop leaves at pop time: no gain measured
+#define MVDB_DUO_PREF 1  // fetch the list of the root the pop leaves at pop time: +1-1.5 % with three waves (none with two)
 #endif
 #ifndef MVDB_DUO_POLL_SLEEP
 #define MVDB_DUO_POLL_SLEEP 1  // s_sleep argument (x64 cycles) between two polls of a mailbox

@@ -1,11 +1,12 @@
 #!/bin/bash
 # usage: tools/bench_variants.sh <n> <bench args...> -- <variant names>; runs bench.py per variant library
 n=$1; shift
+mkdir -p gpurun_out  # bench progress goes to a file there: a silent run is taken to be hung
 args=()
 while [ "$1" != "--" ] && [ $# -gt 0 ]; do args+=("$1"); shift; done
 shift
 for v in default "$@"; do
   if [ "$v" = default ]; then unset MVDB_HIP_LIB; else export MVDB_HIP_LIB=$PWD/minivectordb_amd/lib/libmvdb_hip_$v.so; fi
   echo "== $v"
-  timeout -k 10 300 python bench.py --n $n --cpu-sample 0 --no-recall "${args[@]}" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])" || exit 1
+  timeout -k 10 300 python bench.py --n $n --cpu-sample 0 --no-recall "${args[@]}" 2>>gpurun_out/bench_variants.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])" || exit 1
 done
