@@ -407,6 +407,13 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 				break;
 			}
 			const uint2 root = cand_h[1];
+			// three waves: everything the pop reads (root, last entry, the root's children) in ONE round trip
+			u32x2_t pop_last = {0u, 0u};
+			u32x4_t pop_kids = {0u, 0u, 0u, 0u};
+			if (TRIO) {
+				pop_last = *reinterpret_cast<const lds_u32x2 *>((size_t)((unsigned)(size_t)cand_h + 8u * (unsigned)cand_size));
+				pop_kids = *reinterpret_cast<const lds_u32x4 *>((size_t)((unsigned)(size_t)cand_h + 16u));
+			}
 			const int r_id = rfl((int)root.y);
 			const unsigned r_key = (unsigned)rfl((int)root.x);
 			if (!have_c) {
@@ -430,16 +437,26 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 			int o_id = -1;
 			unsigned o_key = 0;
 			if (cand_size > 0) {
-				const uint2 last = cand_h[cand_size + 1];
-				const int owner = cpipe.issue(lane, cand_size, last.x, last.y);
-				cpipe.tick();  // root step: the root is final
-				o_key = (unsigned)__builtin_amdgcn_readlane((int)cpipe.root_key, owner);
-				o_id = __builtin_amdgcn_readlane((int)cpipe.root_id, owner);
 				if (TRIO) {
-					// the push wave walks the rest of the sift-down (it pushes right after it anyway)
-					const unsigned rest = (unsigned)__builtin_amdgcn_readlane((int)cpipe.a, owner);
-					cpipe.a = 0;
-					duo_publish(&sy->sift_req, u32x4_t{(unsigned)e, rest, last.x, last.y}, lane);
+					// root step of the sift-down (:191-210; HeapPipe::tick at slot 1) on the scalar unit; the
+					// push wave walks the rest (it pushes right after it anyway)
+					const unsigned lk = (unsigned)rfl((int)pop_last.x), li = (unsigned)rfl((int)pop_last.y);
+					const unsigned kl = (unsigned)rfl((int)pop_kids.x), il = (unsigned)rfl((int)pop_kids.y);
+					const unsigned kr = (unsigned)rfl((int)pop_kids.z), ir = (unsigned)rfl((int)pop_kids.w);
+					const bool right = cand_size >= 3 && kr < kl;  // :201 the right child only if strictly better
+					const unsigned kc = right ? kr : kl, ic = right ? ir : il;
+					const bool stop = cand_size < 2 || lk <= kc;  // :206
+					o_key = stop ? lk : kc;
+					o_id = (int)(stop ? li : ic);
+					if (lane == 0) cand_h[1] = make_uint2(o_key, (unsigned)o_id);
+					const unsigned rest = stop ? 0u : 8u * (2u + (right ? 1u : 0u));
+					duo_publish(&sy->sift_req, u32x4_t{(unsigned)e, rest, lk, li}, lane);
+				} else {
+					const uint2 last = cand_h[cand_size + 1];
+					const int owner = cpipe.issue(lane, cand_size, last.x, last.y);
+					cpipe.tick();  // root step: the root is final
+					o_key = (unsigned)__builtin_amdgcn_readlane((int)cpipe.root_key, owner);
+					o_id = __builtin_amdgcn_readlane((int)cpipe.root_id, owner);
 				}
 				if (MVDB_DUO_PREF) {
 					pref_id = o_id;  // its list is needed next unless a new neighbour undercuts it
