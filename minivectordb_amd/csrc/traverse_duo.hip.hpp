@@ -70,6 +70,15 @@ namespace mvdb {
 #ifndef MVDB_DUO_POLL_SLEEP
 #define MVDB_DUO_POLL_SLEEP 1  // s_sleep argument (x64 cycles) between two polls of a mailbox
 #endif
+#ifndef MVDB_DUO_RESULT_PRIO
+#define MVDB_DUO_RESULT_PRIO 3  // s_setprio of the result wave (its admissions are the longest chain): +3.4 %
+#endif
+#ifndef MVDB_DUO_ACCESS_PRIO
+#define MVDB_DUO_ACCESS_PRIO 2  // +1.7 % on top (the push wave at 1 or 2: nothing / worse)
+#endif
+#ifndef MVDB_DUO_PUSH_PRIO
+#define MVDB_DUO_PUSH_PRIO 0
+#endif
 #ifndef MVDB_DUO_POSTPOP_TICKS
 #define MVDB_DUO_POSTPOP_TICKS 0  // measured at 1M x 384, ef 1200: 0 -> 3.87 ms, 4 -> 3.98, 16 -> 4.16
 #endif
@@ -156,6 +165,10 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 	const int qi = blockIdx.x;
 	if (qi >= a.nq) return;
 	const DevIndexView &ix = a.ix;
+#ifdef MVDB_TRAVERSE_PROFILE
+	// where the hardware put this wave: HW_ID bits [5:4] = SIMD, [11:8] = CU, [15:13] = SE (slots 20..22)
+	if (lane == 0 && a.prof) a.prof[(size_t)qi * 24 + 20 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+#endif
 
 	const int ef = a.ef, cand_cap = a.cand_cap;
 	uint2 *res_h = reinterpret_cast<uint2 *>(lds_raw);
@@ -192,6 +205,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 
 	if (wave == 0) {
 		// =========================== access wave ===========================
+		if (MVDB_DUO_ACCESS_PRIO) __builtin_amdgcn_s_setprio(MVDB_DUO_ACCESS_PRIO);
 		QueryRegs<J> Q;
 		load_query<J>(Q, a.q + (size_t)qi * (size_t)ix.dim, ix.dim, lane);
 		int n_dist = 0, n_l0 = 0, n_up = 0;
@@ -546,6 +560,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		// after every admission (adm[e & 1] = {mask, ((e + 1) << 8) | kind << 1 | done, worst}); bits
 		// only ever appear above the ones already set, so pushing the new bits of each snapshot in
 		// ascending order is the list order.  The channel to the access wave is posted from here.
+		if (MVDB_DUO_PUSH_PRIO) __builtin_amdgcn_s_setprio(MVDB_DUO_PUSH_PRIO);
 		int cand_size = 1;  // the access wave pushed the entry point (:453)
 		bool dead = false;
 		for (int e = 0; !dead; e++) {
@@ -621,6 +636,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 	}
 
 	// =========================== result wave ===========================
+	if (MVDB_DUO_RESULT_PRIO) __builtin_amdgcn_s_setprio(MVDB_DUO_RESULT_PRIO);
 	int res_size = 0, cand_size = 1;  // the access wave pushed the entry point (:453)
 	unsigned worst = 0;
 	bool dead = false;

@@ -54,6 +54,13 @@ if __name__ == "__main__":
             print(f"  P {nm:20s} {prof[:, i].mean():12.0f} cyc")
         for i, nm in zip(range(10, 15), ["mem:list", "mem:issue", "mem:background", "mem:rows+dist", "mem:compact"]):
             print(f"  A {nm:20s} {prof[:, i].mean():12.0f} cyc")
+        hw = prof[:, 20:23].astype(np.int64)
+        simd = (hw >> 4) & 3
+        print("SIMD of (access, result, push) wave, share of queries:")
+        for w, nm in enumerate(["access", "result", "push"]):
+            print(f"  {nm:7s}", " ".join(f"simd{i}: {np.mean(simd[:, w] == i):.2f}" for i in range(4)))
+        combos, cnts = np.unique(simd, axis=0, return_counts=True)
+        print("  combinations:", {tuple(int(x) for x in c): int(n) for c, n in zip(combos, cnts)})
         ta = prof[:, :5].sum(1).astype(np.float64) + prof[:, 10:15].sum(1).astype(np.float64)
         tr = prof[:, 5:8].sum(1).astype(np.float64) + prof[:, 15].astype(np.float64)
         print(f"access wave: mean cycles {ta.mean():.0f} max {ta.max():.0f}; result wave: mean {tr.mean():.0f} max {tr.max():.0f}")
