@@ -746,6 +746,15 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	}
+	// The candidate heap's arrays stage the output below, and the access wave still reads the root
+	// after the last channel post (its verification at the pop it then does not take): wait until
+	// it has left.  Its counters are final then, and so is `abort`.
+	if (!dead) {
+		for (int spin = 0; rfl(*reinterpret_cast<volatile int *>(&sy->fin)) == 0 && spin < kDuoSpinLimit; spin++)
+			__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
+		if (rfl(*reinterpret_cast<volatile int *>(&sy->fin)) == 0) dead = true;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
 	if (dead || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
 		if (lane == 0) {
 			sy->abort = 1;
@@ -767,7 +776,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 	}
 
 	// res_to_sorted_full (:317-325): repeated max-heap pops, written back to front, pipelined.
-	// The candidate heap is dead now (the access wave has left); its arrays stage the output.
+	// The candidate heap is dead now (the other waves have left); its arrays stage the output.
 	const int found = res_size;
 	rpipe.drain();
 	// set_only (see TraverseArgs): nothing is cut off, the caller needs the set -> heap order, no sort
@@ -807,9 +816,6 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
 		a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
 	}
-	for (int spin = 0; rfl(*reinterpret_cast<volatile int *>(&sy->fin)) == 0 && spin < kDuoSpinLimit; spin++)
-		__builtin_amdgcn_s_sleep(MVDB_DUO_POLL_SLEEP);
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	if (lane == 0) {
 		a.out_count[qi] = out_count;
 		if (a.ctr) {
