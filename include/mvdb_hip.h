@@ -16,8 +16,20 @@
  *  - "_dev" entry points take DEVICE pointers (HBM) plus a hipStream_t passed as
  *    void* (NULL = default stream) and are asynchronous on that stream; they are
  *    what a resident pipeline (and bench.py) uses.
- *  - one call in flight per handle (the reference serialises every bridge call
- *    behind a promise-chain mutex, wasm-bridge.ts:39-50).
+ *  - host entry points: one call in flight per handle (the reference serialises
+ *    every bridge call behind a promise-chain mutex, wasm-bridge.ts:39-50).
+ *  - `_dev` entry points are issued from ONE host thread at a time, but their
+ *    work may overlap on the device: mvdb_query_many_dev, mvdb_search_many_dev,
+ *    mvdb_prepare_queries_dev, mvdb_rerank_many_dev and mvdb_merge_topk_dev keep
+ *    their intermediates per stream (up to 4 streams; a fifth stream takes over
+ *    the least recently assigned set after that set's stream has drained;
+ *    mvdb_release_stream gives a set back before its stream is destroyed).
+ *    mvdb_scan_many_dev uses one scratch set per handle: scans on different
+ *    streams must not overlap.
+ *  - a traversal that gives up on a query (bounded waits of its wave protocol)
+ *    reports out_count = -1 / out_n = -1 for it and raises the handle's error
+ *    word: host entry points then return 0; `_dev` callers call
+ *    mvdb_check_errors() after synchronising.
  *  - there is NO CPU fallback: without a HIP device every compute call fails.
  */
 #ifndef MVDB_HIP_H
@@ -62,7 +74,7 @@ int mvdb_create(const mvdb_config *cfg, mvdb_index **out);
 void mvdb_destroy(mvdb_index *h);
 /* text of the last failure on this handle (or of mvdb_create when h == NULL) */
 const char *mvdb_last_error(const mvdb_index *h);
-/* 1 when a gfx950-class HIP device is usable by this process */
+/* 1 when a HIP device whose gcnArchName starts with "gfx950" is visible to this process */
 int mvdb_device_available(void);
 
 /* ---- index state (WasmBridge getters/setters) ---------------------------- */
@@ -73,6 +85,7 @@ void mvdb_set_results_cap(mvdb_index *h, int cap); /* set_results_cap, hnsw.ts:7
 int mvdb_get_results_cap(const mvdb_index *h);     /* get_results_cap, hnsw.ts:86  */
 int mvdb_has_node(const mvdb_index *h, int id);    /* has_node, hnsw.ts:135        */
 int mvdb_get_max_elements(const mvdb_index *h);    /* get_max_elements, hnsw.ts:103 */
+int mvdb_get_dim(const mvdb_index *h);             /* DIM, assembly/config.ts:16 (bindings size buffers by it) */
 int mvdb_element_count(const mvdb_index *h);
 int mvdb_was_ef_clamped(const mvdb_index *h);      /* was_ef_clamped, hnsw.ts:94   */
 void mvdb_clear_ef_clamped(mvdb_index *h);         /* clear_ef_clamped, hnsw.ts:98 */
@@ -159,7 +172,7 @@ double mvdb_to_score(double l2, int mode);
 int mvdb_dist_many(mvdb_index *h, const int8_t *q, int nq, const int32_t *ids, int per_q, int metric,
                    int32_t *out);
 /* exact brute-force int8 scan over all present nodes; order (dist asc, id asc)
- * for L2, (dot desc, id asc) for dot; k <= 128.  No reference counterpart
+ * for L2, (dot desc, id asc) for dot; k <= 32, dim <= 512.  No reference counterpart
  * (north_star kernel #2); parity target is the oracle's mvo_scan_many. */
 int mvdb_scan_many(mvdb_index *h, const int8_t *q, int nq, int k, int metric, int32_t *out_ids,
                    int32_t *out_val, int32_t *out_count);
@@ -172,6 +185,24 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2, const int32_t *d_n,
                         int parts, int nq, int topk, int32_t *d_out_ids, double *d_out_l2,
                         int32_t *d_out_n, void *stream);
+
+/* ---- engine state beyond the WASM surface ---------------------------------- */
+/* Kernel variants of the timed path (handle state, read at launch): traverse_waves
+ * 0 = default (3 waves per query when M_MAX0 <= 64), 1/2/3 force a variant (all
+ * bit-identical, tests/test_gpu_traverse_modes.py); rerank_waves 0 = default (4),
+ * 2 = small workgroups that fit beside a running traversal.  No reference counterpart. */
+int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves);
+/* After the caller synchronised its stream(s): 1 = no kernel of this handle raised the
+ * error word since the last check, 0 = one did (mvdb_last_error has the text).  Clears it.
+ * The WASM cannot fail this way; the reference's nearest analogue is the abort import
+ * that only logs (wasm-bridge.ts:57-59). */
+int mvdb_check_errors(mvdb_index *h);
+/* Test hook: query index `query` of every following traversal launch takes the abort
+ * path (-1 = off). */
+void mvdb_debug_inject_abort(mvdb_index *h, int query);
+/* Synchronise `stream` and give its per-stream scratch set back (call before
+ * destroying a stream that was passed to a `_dev` entry point). */
+int mvdb_release_stream(mvdb_index *h, void *stream);
 
 /* ---- measurement ----------------------------------------------------------- */
 /* average device time (ms) of the last launch of each stage, measured with HIP

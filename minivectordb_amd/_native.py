@@ -38,6 +38,7 @@ SYMBOLS = [
     ("mvdb_get_results_cap", _i, [_vp]),
     ("mvdb_has_node", _i, [_vp, _i]),
     ("mvdb_get_max_elements", _i, [_vp]),
+    ("mvdb_get_dim", _i, [_vp]),
     ("mvdb_element_count", _i, [_vp]),
     ("mvdb_was_ef_clamped", _i, [_vp]),
     ("mvdb_clear_ef_clamped", None, [_vp]),
@@ -64,6 +65,10 @@ SYMBOLS = [
     ("mvdb_scan_many", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     ("mvdb_scan_many_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_merge_topk_dev", _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("mvdb_set_tuning", _i, [_vp, _i, _i]),
+    ("mvdb_check_errors", _i, [_vp]),
+    ("mvdb_debug_inject_abort", None, [_vp, _i]),
+    ("mvdb_release_stream", _i, [_vp, _vp]),
     ("mvdb_enable_timing", None, [_vp, _i]),
     ("mvdb_last_stage_ms", _f, [_vp, _i]),
     ("mvdb_stage_stats", _i, [_vp, _i, _vp, _vp, _i]),

@@ -113,6 +113,40 @@ class HipBridge:
     def elementCount(self) -> int:
         return self._L.mvdb_element_count(self.handle)
 
+    def setTuning(self, traverse_waves: int = 0, rerank_waves: int = 0) -> None:
+        """Kernel variants of the timed path (mvdb_set_tuning); 0 = the engine's default."""
+        with self._lock:
+            self._check(self._L.mvdb_set_tuning(self.handle, int(traverse_waves), int(rerank_waves)))
+
+    def checkErrors(self) -> None:
+        """After synchronising `_dev` work: raise if a kernel of this handle reported a failure."""
+        with self._lock:
+            self._check(self._L.mvdb_check_errors(self.handle))
+
+    def _dim(self) -> int:
+        return int(self._cfg["dim"])
+
+    def _rows(self, a, dtype, what: str) -> np.ndarray:
+        """nq x dim array of `dtype`; a wrong row length is an error, never a reinterpretation."""
+        a = np.ascontiguousarray(a, dtype)
+        dim = self._dim()
+        if a.ndim == 1:
+            if a.size % dim:
+                raise MvdbError(f"{what}: length {a.size} is not a multiple of dim={dim}")
+            a = a.reshape(-1, dim)
+        if a.ndim != 2 or a.shape[1] != dim:
+            raise MvdbError(f"{what}: expected rows of dim={dim}, got shape {a.shape}")
+        return a
+
+    def _allow(self, allow_bitmap):
+        if allow_bitmap is None:
+            return None
+        allow = np.ascontiguousarray(allow_bitmap, np.uint32).reshape(-1)
+        need = (max(self.getMaxElements(), 1) + 31) // 32
+        if allow.size < need:
+            raise MvdbError(f"allow bitmap too short: {allow.size} words for {self.getMaxElements()} ids ({need} needed)")
+        return allow
+
     def reinitIndex(self, capacity: int) -> None:   # :199-240
         with self._lock:
             if self._cfg is None:
@@ -158,9 +192,7 @@ class HipBridge:
 
     # ---- search ---------------------------------------------------------------
     def searchManyArrays(self, vectorsI8, k: int, with_counters: bool = False):
-        q = np.ascontiguousarray(vectorsI8, np.int8)
-        dim = int(self._cfg["dim"])
-        q = q.reshape(-1, dim)
+        q = self._rows(vectorsI8, np.int8, "searchMany")
         nq, kk = q.shape[0], max(int(k), 1)
         ids = np.full((nq, kk), -1, np.int32)
         dist = np.zeros((nq, kk), np.float32)
@@ -179,7 +211,10 @@ class HipBridge:
                 for q in range(ids.shape[0])]
 
     def search(self, vectorI8, k: int) -> List[dict]:  # :301-321
-        return self.searchMany(np.asarray(vectorI8, np.int8).reshape(1, -1), k)[0]
+        v = np.asarray(vectorI8, np.int8).reshape(-1)
+        if v.size != self._dim():
+            raise MvdbError(f"search: vector length {v.size} != dim {self._dim()}")
+        return self.searchMany(v.reshape(1, -1), k)[0]
 
     # ---- dump -----------------------------------------------------------------
     def save(self, filePath: str) -> None:          # :357-375
@@ -212,12 +247,12 @@ class HipBridge:
 
     # ---- stages beyond the WasmBridge surface (compute parts of MiniVectorDB) ----
     def attachF32(self, base_f32, resident: bool = True) -> None:
-        base = np.ascontiguousarray(base_f32, np.float32)
+        base = self._rows(base_f32, np.float32, "attachF32")
         with self._lock:
             self._check(self._L.mvdb_attach_f32(self.handle, _ptr(base), base.shape[0], 1 if resident else 0))
 
     def prepareQueries(self, q_f32):
-        q = np.ascontiguousarray(q_f32, np.float32)
+        q = self._rows(q_f32, np.float32, "prepareQueries")
         qn = np.empty_like(q)
         qi = np.empty(q.shape, np.int8)
         with self._lock:
@@ -225,14 +260,16 @@ class HipBridge:
         return qn, qi
 
     def rerankMany(self, q_f32, cand, cand_count, ann_k: int, topk: int, allow_bitmap=None):
-        q = np.ascontiguousarray(q_f32, np.float32)
+        q = self._rows(q_f32, np.float32, "rerankMany")
         cand = np.ascontiguousarray(cand, np.int32)
-        cc = np.ascontiguousarray(cand_count, np.int32)
+        cc = np.ascontiguousarray(cand_count, np.int32).reshape(-1)
         nq = q.shape[0]
+        if cand.ndim != 2 or cand.shape[0] != nq or cc.size != nq:
+            raise MvdbError(f"rerankMany: {nq} queries but cand {cand.shape}, cand_count {cc.shape}")
         out_ids = np.full((nq, max(topk, 1)), -1, np.int32)
         out_l2 = np.zeros((nq, max(topk, 1)), np.float64)
         out_n = np.zeros(nq, np.int32)
-        allow = None if allow_bitmap is None else np.ascontiguousarray(allow_bitmap, np.uint32)
+        allow = self._allow(allow_bitmap)
         with self._lock:
             self._check(self._L.mvdb_rerank_many(self.handle, _ptr(q), nq, _ptr(cand), _ptr(cc), cand.shape[1],
                                                  int(ann_k), _ptr(allow), int(topk), _ptr(out_ids), _ptr(out_l2),
@@ -240,22 +277,24 @@ class HipBridge:
         return out_ids, out_l2, out_n
 
     def queryMany(self, q_f32, topk: int, ef_search: int, ann_k: int, allow_bitmap=None, with_counters=False):
-        q = np.ascontiguousarray(q_f32, np.float32)
+        q = self._rows(q_f32, np.float32, "queryMany")
         nq = q.shape[0]
         out_ids = np.full((nq, max(topk, 1)), -1, np.int32)
         out_l2 = np.zeros((nq, max(topk, 1)), np.float64)
         out_n = np.zeros(nq, np.int32)
         ctr = np.zeros((nq, 4), np.int32)
-        allow = None if allow_bitmap is None else np.ascontiguousarray(allow_bitmap, np.uint32)
+        allow = self._allow(allow_bitmap)
         with self._lock:
             self._check(self._L.mvdb_query_many(self.handle, _ptr(q), nq, int(topk), int(ef_search), int(ann_k),
                                                 _ptr(allow), _ptr(out_ids), _ptr(out_l2), _ptr(out_n), _ptr(ctr)))
         return (out_ids, out_l2, out_n, ctr) if with_counters else (out_ids, out_l2, out_n)
 
     def distMany(self, q_i8, ids, metric: str = "l2"):
-        q = np.ascontiguousarray(q_i8, np.int8)
+        q = self._rows(q_i8, np.int8, "distMany")
         ids = np.ascontiguousarray(ids, np.int32)
         nq, per_q = ids.shape
+        if q.shape[0] != nq:
+            raise MvdbError(f"distMany: {q.shape[0]} queries but {nq} id rows")
         out = np.zeros((nq, per_q), np.int32)
         with self._lock:
             self._check(self._L.mvdb_dist_many(self.handle, _ptr(q), nq, _ptr(ids), per_q,
@@ -263,7 +302,7 @@ class HipBridge:
         return out
 
     def scanMany(self, q_i8, k: int, metric: str = "l2"):
-        q = np.ascontiguousarray(q_i8, np.int8)
+        q = self._rows(q_i8, np.int8, "scanMany")
         nq = q.shape[0]
         ids = np.full((nq, max(k, 1)), -1, np.int32)
         val = np.zeros((nq, max(k, 1)), np.int32)

@@ -210,6 +210,14 @@ struct mvdb_index {
 	DevBuf st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
 		st_misc, scan_part, prof_buf;
 
+	// tuning knobs of the timed path (mvdb_set_tuning); 0 = the engine's default
+	int traverse_waves = 0;  // 1, 2 or 3 waves per query
+	int rerank_waves = 0;    // 2 or 4 waves per rerank workgroup
+	// error word the kernels raise (host-pinned, device-mapped): bit 0 = a traversal aborted a query
+	int *err_host = nullptr;
+	int *err_dev = nullptr;
+	int inject_abort_q = -1;  // mvdb_debug_inject_abort
+
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[4];
 	float stage_ms[4] = {-1.f, -1.f, -1.f, -1.f};
@@ -221,6 +229,7 @@ struct mvdb_index {
 	{
 		(void)hipFree(f32_dev);
 		if (f32_pinned) (void)hipHostFree(f32_pinned);
+		if (err_host) (void)hipHostFree(err_host);
 		for (auto &v : ev_pairs)
 			for (auto &pr : v) {
 				(void)hipEventDestroy(pr.first);
@@ -253,6 +262,33 @@ void bridge_reinit(mvdb_index *h)
 int ensure_device(mvdb_index *h)
 {
 	HIP_OK(h, hipSetDevice(h->device));
+	if (!h->err_host) {
+		HIP_OK(h, hipHostMalloc(reinterpret_cast<void **>(&h->err_host), 64, hipHostMallocMapped));
+		*h->err_host = 0;
+		void *dp = nullptr;
+		HIP_OK(h, hipHostGetDevicePointer(&dp, h->err_host, 0));
+		h->err_dev = static_cast<int *>(dp);
+	}
+	return 1;
+}
+
+// after a synchronisation: did a kernel of this handle raise the error word?  Clears it.
+int check_device_errors(mvdb_index *h)
+{
+	if (!h->err_host) return 1;
+	const int e = __atomic_exchange_n(h->err_host, 0, __ATOMIC_ACQ_REL);
+	if (e == 0) return 1;
+	h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
+	return 0;
+}
+
+// hipFuncSetAttribute once per (kernel, device) and LDS high-water mark, not once per launch
+int set_max_lds(mvdb_index *h, const void *fn, int (&mark)[16], size_t lds)
+{
+	const int d = h->device & 15;
+	if ((int)lds <= mark[d]) return 1;
+	HIP_OK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	mark[d] = (int)lds;
 	return 1;
 }
 
@@ -313,8 +349,8 @@ void resolve_stage(mvdb_index *h, int stage)
 template <int J, bool FULL>
 int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
 {
-	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&traverse_kernel<J, FULL>),
-	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	static int mark[16] = {0};
+	if (!set_max_lds(h, reinterpret_cast<const void *>(&traverse_kernel<J, FULL>), mark, lds)) return 0;
 	hipLaunchKernelGGL((traverse_kernel<J, FULL>), dim3(a.nq), dim3(64), lds, s, a);
 	HIP_OK(h, hipGetLastError());
 	return 1;
@@ -323,37 +359,31 @@ int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStrea
 template <int J, bool FULL, int WAVES>
 int launch_traverse_duo_w(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
 {
-	HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&traverse_duo_kernel<J, FULL, WAVES>),
-	                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	static int mark[16] = {0};
+	if (!set_max_lds(h, reinterpret_cast<const void *>(&traverse_duo_kernel<J, FULL, WAVES>), mark, lds)) return 0;
 	hipLaunchKernelGGL((traverse_duo_kernel<J, FULL, WAVES>), dim3(a.nq), dim3(64 * WAVES), lds, s, a);
 	HIP_OK(h, hipGetLastError());
 	return 1;
 }
 
-int traverse_waves_forced()
-{
-	const char *e = std::getenv("MVDB_TRAVERSE_WAVES");
-	return e ? std::atoi(e) : 0;
-}
-
 template <int J, bool FULL>
 int launch_traverse_duo_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
 {
-	if (traverse_waves_forced() == 2) return launch_traverse_duo_w<J, FULL, 2>(h, a, lds, s);
+	if (h->traverse_waves == 2) return launch_traverse_duo_w<J, FULL, 2>(h, a, lds, s);
 	return launch_traverse_duo_w<J, FULL, 3>(h, a, lds, s);
 }
 
-// Several waves per query (traverse_duo.hip.hpp: three by default, MVDB_TRAVERSE_WAVES=2 for the
-// two-wave variant) whenever a neighbour list fits one 64-lane chunk; MVDB_TRAVERSE_WAVES=1
+// Several waves per query (traverse_duo.hip.hpp: three by default, mvdb_set_tuning(h, 2, ..) for the
+// two-wave variant) whenever a neighbour list fits one 64-lane chunk; mvdb_set_tuning(h, 1, ..)
 // selects the one-wave kernel for A/B timing.
-bool traverse_use_duo(const TraverseArgs &a)
+bool traverse_use_duo(const mvdb_index *h, const TraverseArgs &a)
 {
-	return a.ix.m0 <= kDuoMaxM0 && traverse_waves_forced() != 1;
+	return a.ix.m0 <= kDuoMaxM0 && h->traverse_waves != 1;
 }
 
 int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 {
-	const bool duo = traverse_use_duo(a);
+	const bool duo = traverse_use_duo(h, a);
 	const size_t lds = duo ? traverse_duo_lds_bytes(a.ef, a.cand_cap) : traverse_lds_bytes(a.ef, a.cand_cap);
 	const int stride = a.ix.row_stride;
 	const int J = (stride + 127) / 128;
@@ -387,7 +417,12 @@ int mvdb_device_available(void)
 {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-	return n > 0;
+	for (int d = 0; d < n; d++) {  // the code object is gfx950 only
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+		if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) return 1;
+	}
+	return 0;
 }
 
 int mvdb_create(const mvdb_config *cfg, mvdb_index **out)
@@ -435,6 +470,7 @@ void mvdb_set_results_cap(mvdb_index *h, int cap)
 int mvdb_get_results_cap(const mvdb_index *h) { return h->g.results_cap; }
 int mvdb_has_node(const mvdb_index *h, int id) { return h->g.present(id) ? 1 : 0; }
 int mvdb_get_max_elements(const mvdb_index *h) { return h->g.max_elements; }
+int mvdb_get_dim(const mvdb_index *h) { return h->cfg.dim; }
 int mvdb_element_count(const mvdb_index *h) { return h->g.element_count; }
 int mvdb_was_ef_clamped(const mvdb_index *h) { return h->g.ef_clamped ? 1 : 0; }
 void mvdb_clear_ef_clamped(mvdb_index *h) { h->g.ef_clamped = false; }
@@ -552,10 +588,9 @@ mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
 		}
 	mvdb_index::StreamScratch &c = h->ss[h->ss_next];
 	h->ss_next = (h->ss_next + 1) % kStreamSets;
-	if (hipStreamSynchronize(c.stream) != hipSuccess) {
-		h->set_error("hipStreamSynchronize failed while re-assigning per-stream scratch");
-		return nullptr;
-	}
+	// the old owner may have been destroyed by the caller already: nothing of it can still be in
+	// flight then, so an error here only means the handle is stale
+	if (hipStreamSynchronize(c.stream) != hipSuccess) (void)hipGetLastError();
 	c.stream = s;
 	return &c;
 }
@@ -615,6 +650,8 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		a.out_count = d_out_count + q0;
 		a.ctr = d_ctr ? d_ctr + q0 : nullptr;
 		a.prof = nullptr;
+		a.err = h->err_dev;
+		a.inject_abort_q = h->inject_abort_q >= q0 && h->inject_abort_q < q0 + n ? h->inject_abort_q - q0 : -1;
 #ifdef MVDB_TRAVERSE_PROFILE
 		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 192)) + (size_t)q0 * 24;
 #endif
@@ -653,11 +690,7 @@ int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out
 	if (!mvdb_search_many_dev(h, d_q, nq, k, d_ids, d_dist, d_cnt, d_ctr, nullptr)) return 0;
 	HIP_OK(h, hipDeviceSynchronize());
 	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
-	for (int i = 0; i < nq; i++)
-		if (out_count[i] < 0) {  // traverse_duo.hip.hpp: a wave gave up waiting, or the pop check failed
-			h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
-			return 0;
-		}
+	if (!check_device_errors(h)) return 0;  // traverse_duo.hip.hpp: a wave gave up waiting, or the pop check failed
 	if (k > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_ids, nk * 4, hipMemcpyDeviceToHost));
 		HIP_OK(h, hipMemcpy(out_dist, d_dist, nk * 4, hipMemcpyDeviceToHost));
@@ -705,9 +738,8 @@ int mvdb_rerank_many_dev(mvdb_index *h, const float *d_q_f32, int nq, const int3
 	a.out_l2 = d_out_l2;
 	a.out_n = d_out_n;
 	const int cap = std::min(stride, ann_k);
-	// MVDB_RERANK_WAVES=2: small workgroups that fit beside a running traversal (pipelined batches)
-	const char *rw = std::getenv("MVDB_RERANK_WAVES");
-	const int waves = (rw && std::atoi(rw) == 2) ? 2 : kRerankWavesDefault;
+	// mvdb_set_tuning(h, .., 2): small workgroups that fit beside a running traversal (batches in flight)
+	const int waves = h->rerank_waves == 2 ? 2 : kRerankWavesDefault;
 	const size_t lds = rerank_lds_bytes(a.dim, cap, waves);
 	if (lds > 160 * 1024) {
 		h->set_error("rerank: candidate list too long for LDS");
@@ -715,7 +747,8 @@ int mvdb_rerank_many_dev(mvdb_index *h, const float *d_q_f32, int nq, const int3
 	}
 	const void *fn = waves == 2 ? reinterpret_cast<const void *>(&rerank_kernel<2>)
 	                            : reinterpret_cast<const void *>(&rerank_kernel<kRerankWavesDefault>);
-	HIP_OK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	static int mark2[16] = {0}, mark4[16] = {0};
+	if (!set_max_lds(h, fn, waves == 2 ? mark2 : mark4, lds)) return 0;
 	StageTimer t(h, 2, s);
 	if (waves == 2) hipLaunchKernelGGL(rerank_kernel<2>, dim3(nq), dim3(128), lds, s, a, cap);
 	else hipLaunchKernelGGL(rerank_kernel<kRerankWavesDefault>, dim3(nq), dim3(kRerankWavesDefault * 64), lds, s, a, cap);
@@ -859,6 +892,7 @@ int mvdb_query_many(mvdb_index *h, const float *q_f32, int nq, int topk, int ef_
 	HIP_OK(h, hipMemcpy(d_in, q_f32, nqd * 4, hipMemcpyHostToDevice));
 	if (!mvdb_query_many_dev(h, d_in, nq, topk, ef_search, ann_k, d_allow, d_oi, d_ol, d_on, d_ctr, nullptr)) return 0;
 	HIP_OK(h, hipDeviceSynchronize());
+	if (!check_device_errors(h)) return 0;
 	HIP_OK(h, hipMemcpy(out_n, d_on, (size_t)nq * 4, hipMemcpyDeviceToHost));
 	if (topk > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_oi, (size_t)nq * topk * 4, hipMemcpyDeviceToHost));
@@ -975,11 +1009,6 @@ int mvdb_scan_many(mvdb_index *h, const int8_t *q, int nq, int k, int metric, in
 	if (!mvdb_scan_many_dev(h, d_q, nq, k, metric, d_ids, d_val, d_cnt, nullptr)) return 0;
 	HIP_OK(h, hipDeviceSynchronize());
 	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
-	for (int i = 0; i < nq; i++)
-		if (out_count[i] < 0) {  // traverse_duo.hip.hpp: a wave gave up waiting, or the pop check failed
-			h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
-			return 0;
-		}
 	if (k > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
 		HIP_OK(h, hipMemcpy(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
@@ -1019,6 +1048,34 @@ int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 192, hipMemcpyDeviceToHost) == hipSuccess;
 }
 #endif
+int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)
+{
+	if (traverse_waves < 0 || traverse_waves > 3 || (rerank_waves != 0 && rerank_waves != 2 && rerank_waves != 4)) {
+		h->set_error("mvdb_set_tuning: traverse_waves must be 0..3, rerank_waves 0, 2 or 4");
+		return 0;
+	}
+	h->traverse_waves = traverse_waves;
+	h->rerank_waves = rerank_waves;
+	return 1;
+}
+
+int mvdb_check_errors(mvdb_index *h) { return check_device_errors(h); }
+
+void mvdb_debug_inject_abort(mvdb_index *h, int query) { h->inject_abort_q = query; }
+
+int mvdb_release_stream(mvdb_index *h, void *stream)
+{
+	if (!ensure_device(h)) return 0;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	for (auto &c : h->ss)
+		if (c.used && c.stream == s) {
+			HIP_OK(h, hipStreamSynchronize(s));
+			c.used = false;
+			c.stream = nullptr;
+		}
+	return 1;
+}
+
 void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }
 float mvdb_last_stage_ms(mvdb_index *h, int stage)
 {

@@ -503,11 +503,10 @@ void HostGraph::overwrite_neighbors(int id, int layer, int picked, BuildScratch 
 }
 
 // the per-layer connect loop of insert, :812-827
-void HostGraph::link_new_node(int id, int lvl, BuildScratch &s, bool par)
+void HostGraph::link_new_node(int id, int lvl, BuildScratch &s, bool par, int entry, int top)
 {
 	const int8_t *q = row(id);
-	int cur = entry_point;
-	const int top = max_level;
+	int cur = entry;
 	float cur_d = dist_l2_sq(q, row(cur), cfg.dim);  // :772
 	greedy(q, cur, cur_d, top, lvl, s, par);         // :775-810
 	for (int l = std::min(lvl, top); l >= 0; l--) {
@@ -559,7 +558,7 @@ void HostGraph::insert(int id, const int8_t *v)
 		element_count++;
 		return;
 	}
-	link_new_node(id, lvl, *main_, false);
+	link_new_node(id, lvl, *main_, false, entry_point, max_level);
 	if (lvl > max_level) {  // :829-832
 		max_level = lvl;
 		entry_point = id;
@@ -656,9 +655,11 @@ void HostGraph::build_parallel(const int8_t *packed, int n, int threads)
 				if (global_lock_.compare_exchange_weak(exp, 1, std::memory_order_acquire)) break;
 				while (global_lock_.load(std::memory_order_relaxed)) __builtin_ia32_pause();
 			}
-			const bool raises = lvl > max_level;
+			// (entry_point, max_level) are read as a pair under the lock that guards their update
+			const int entry = entry_point, top = max_level;
+			const bool raises = lvl > top;
 			if (!raises) global_lock_.store(0, std::memory_order_release);
-			link_new_node(id, lvl, *s, true);
+			link_new_node(id, lvl, *s, true, entry, top);
 			if (raises) {
 				max_level = lvl;
 				entry_point = id;
@@ -673,7 +674,7 @@ void HostGraph::build_parallel(const int8_t *packed, int n, int threads)
 		while (next.load() < prefix) {
 			const int id = next.fetch_add(1);
 			const int lvl = lv[id];
-			link_new_node(id, lvl, *main_, true);
+			link_new_node(id, lvl, *main_, true, entry_point, max_level);
 			if (lvl > max_level) {
 				max_level = lvl;
 				entry_point = id;

@@ -100,7 +100,7 @@ private:
 	int add_connection(int src, int dst, int layer, bool defer_victim);  // hnsw.ts:593-645
 	void remove_connection(int src, int dst, int layer);             // hnsw.ts:648-678
 	void overwrite_neighbors(int id, int layer, int picked, BuildScratch &s);  // hnsw.ts:681-716
-	void link_new_node(int id, int lvl, BuildScratch &s, bool par);
+	void link_new_node(int id, int lvl, BuildScratch &s, bool par, int entry, int top);
 	void lock(int id);
 	void unlock(int id);
 };

@@ -96,6 +96,14 @@ __global__ __launch_bounds__(kRerankWaves * 64) void rerank_kernel(RerankArgs a,
 
 	// ---- filter in ANN order, keep at most ann_k (:606-621); compact kept ids into key_id[]
 	int cc = a.cand_count[qi];
+	if (cc < 0) {  // the traversal aborted this query (traverse_report_abort): the failure stays visible, block-uniform
+		if (tid == 0) a.out_n[qi] = -1;
+		for (int j = tid; j < a.topk; j += kRerankThreads) {
+			a.out_ids[(size_t)qi * a.topk + j] = -1;
+			a.out_l2[(size_t)qi * a.topk + j] = 0.0;
+		}
+		return;
+	}
 	if (cc > a.stride) cc = a.stride;
 	if (tid == 0) misc[0] = 0;
 	__syncthreads();

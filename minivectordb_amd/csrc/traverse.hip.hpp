@@ -334,7 +334,32 @@ struct TraverseArgs {
 	int32_t *out_count;   // nq
 	mvdb_query_counters *ctr;  // nq or null
 	unsigned long long *prof;  // diagnostic builds only (MVDB_TRAVERSE_PROFILE): nq x 16 cycle sums
+	int *err;             // device-visible error word of the handle (host-pinned): bit 0 = a query aborted
+	int inject_abort_q;   // test hook (mvdb_debug_inject_abort): this query takes the abort path; -1 = none
 };
+
+// An aborted query (traverse_duo's bounded waits, or the test hook) is reported three ways: out_count = -1,
+// n_found = -1, and bit 0 of the handle's error word, which every host entry point checks after its
+// synchronisation and mvdb_check_errors() exposes to `_dev` callers.
+__device__ __forceinline__ void traverse_report_abort(const TraverseArgs &a, int qi, int lane)
+{
+	if (lane == 0) {
+		a.out_count[qi] = -1;
+		if (a.ctr) {
+			mvdb_query_counters c;
+			c.n_dist = 0;
+			c.n_l0lists = 0;
+			c.n_upperlists = 0;
+			c.n_found = -1;
+			a.ctr[qi] = c;
+		}
+		if (a.err) __hip_atomic_fetch_or(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	for (int i = lane; i < a.k; i += 64) {
+		a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
+		a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
+	}
+}
 
 #ifdef MVDB_TRAVERSE_PROFILE
 #define MVDB_STAMP(slot)                                        \
@@ -363,6 +388,10 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 	const int qi = blockIdx.x;
 	if (qi >= a.nq) return;
 	const DevIndexView &ix = a.ix;
+	if (qi == a.inject_abort_q) {  // test hook: the one-wave kernel has no abort path of its own
+		traverse_report_abort(a, qi, lane);
+		return;
+	}
 
 	const int ef = a.ef, cand_cap = a.cand_cap;
 	uint2 *res_h = reinterpret_cast<uint2 *>(lds_raw);

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 
 		HeapPipe<true> cpipe;
 		cpipe.base = (unsigned)(size_t)cand_h;
-		bool dead = false;
+		bool dead = qi == a.inject_abort_q;  // test hook: the abort protocol runs as after a failed wait
 		int res_size = 0;  // tracked from the admitted masks
 		unsigned worst = 0;
 		int sift_e = 0;        // last pop issued
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		int c_id = cur;
 		unsigned c_d = cur_d;
 		bool have_c = true, published = false;
-		for (;;) {
+		for (; !dead;) {
 			int n = 0;
 			published = false;
 			// what the prediction below needs from this list alone; formed right after the record is
@@ -756,22 +756,8 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	}
 	if (dead || rfl(*reinterpret_cast<volatile int *>(&sy->abort))) {
-		if (lane == 0) {
-			sy->abort = 1;
-			a.out_count[qi] = -1;
-			if (a.ctr) {
-				mvdb_query_counters c;
-				c.n_dist = 0;
-				c.n_l0lists = 0;
-				c.n_upperlists = 0;
-				c.n_found = -1;
-				a.ctr[qi] = c;
-			}
-		}
-		for (int i = lane; i < a.k; i += 64) {
-			a.out_ids[(size_t)qi * (size_t)a.k + i] = -1;
-			a.out_dist[(size_t)qi * (size_t)a.k + i] = 0.f;
-		}
+		if (lane == 0) sy->abort = 1;
+		traverse_report_abort(a, qi, lane);
 		return;
 	}
 

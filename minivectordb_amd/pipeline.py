@@ -41,8 +41,8 @@ class ResidentSearcher:
 
     # ---- consecutive batches, software-pipelined ---------------------------------------------
     # The traversal is latency-bound and leaves HBM idle; the rerank is bandwidth-bound.  With
-    # batch i's rerank on a second stream, it runs under batch i+1's traversal (set
-    # MVDB_RERANK_WAVES=2 so that a rerank workgroup fits beside four traversal workgroups on a
+    # batch i's rerank on a second stream, it runs under batch i+1's traversal (call
+    # bridge.setTuning(rerank_waves=2) so that a rerank workgroup fits beside four traversal workgroups on a
     # CU).  Results of a submitted batch are valid after `wait(slot)`/`drain()`.
     def _pipe_init(self, nq: int, dim: int, ann_k: int, depth: int = 2):
         key = (nq, dim, ann_k, depth)
@@ -135,7 +135,7 @@ class ResidentSearcher:
         elif s["has_consumer"]:
             S.wait_event(s["consumed"])  # whoever read this slot's outputs two batches ago (release())
         vp = C.c_void_p
-        # the engine keeps one set of intermediates (and visited bitmaps) per stream, two streams at most
+        # the engine keeps one set of intermediates (and visited bitmaps) per stream, four streams at most
         self.b._check(L.mvdb_query_many_dev(h, vp(q_f32.data_ptr()), nq, self.topk, int(ef_search), int(ann_k),
                                             vp(allow.data_ptr()) if allow is not None else None,
                                             vp(s["ids"].data_ptr()), vp(s["l2"].data_ptr()), vp(s["n"].data_ptr()),
@@ -155,6 +155,12 @@ class ResidentSearcher:
         s = self._slots[slot]
         s["consumed"].record(torch.cuda.current_stream(self.device))
         s["has_consumer"] = True
+
+    def check(self):
+        """Synchronise the device and raise if a traversal of this handle aborted a query (its results
+        carry n = -1; mvdb_check_errors).  Call outside timed regions."""
+        torch.cuda.synchronize(self.device)
+        self.b.checkErrors()
 
     def drain(self):
         cur = torch.cuda.current_stream(self.device)

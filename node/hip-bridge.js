@@ -76,12 +76,22 @@ class HipBridge {
 		});
 	}
 
+	// every vector handed to the addon has the configured dim (the WASM copies DIM bytes whatever the
+	// array holds, wasm-bridge.ts:151-160; here a wrong length is an error, not an out-of-bounds read)
+	_vec(vectorI8, what) {
+		const dim = this.currentConfig ? this.currentConfig.dim | 0 : 0;
+		if (!vectorI8 || vectorI8.length !== dim) {
+			throw new Error(`${what}: vector length ${vectorI8 ? vectorI8.length : 0} != dim ${dim}`);
+		}
+		return vectorI8 instanceof Int8Array ? vectorI8 : Int8Array.from(vectorI8);
+	}
+
 	async insert(id, vectorI8) { // :242
-		await this.withLock(() => { native.insertManyPacked(this.h, Int32Array.of(id), Int8Array.from(vectorI8)); });
+		await this.withLock(() => { native.insertManyPacked(this.h, Int32Array.of(id), this._vec(vectorI8, "insert")); });
 	}
 	async insertMany(pairs) { // :253
 		await this.withLock(() => {
-			for (const p of pairs) native.insertManyPacked(this.h, Int32Array.of(p.id), Int8Array.from(p.vectorI8));
+			for (const p of pairs) native.insertManyPacked(this.h, Int32Array.of(p.id), this._vec(p.vectorI8, "insertMany"));
 		});
 	}
 	async insertManyPacked(ids, packed, dim) { // :268-288
@@ -93,7 +103,7 @@ class HipBridge {
 	}
 	async updateVector(id, vectorI8) { // :290 update_and_reconnect: an absent id is a silent no-op
 		await this.withLock(() => {
-			if (native.hasNode(this.h, id | 0)) native.insertManyPacked(this.h, Int32Array.of(id), Int8Array.from(vectorI8));
+			if (native.hasNode(this.h, id | 0)) native.insertManyPacked(this.h, Int32Array.of(id), this._vec(vectorI8, "updateVector"));
 		});
 	}
 
@@ -109,15 +119,15 @@ class HipBridge {
 		return out;
 	}
 	async search(vectorI8, k) { // :301
-		return this.withLock(() => this._decode(native.searchMany(this.h, Int8Array.from(vectorI8), 1, k | 0), 1, k | 0)[0]);
+		return this.withLock(() => this._decode(native.searchMany(this.h, this._vec(vectorI8, "search"), 1, k | 0), 1, k | 0)[0]);
 	}
 	async searchMany(vectorsI8, k) { // :326
 		return this.withLock(() => {
 			const nq = vectorsI8.length;
 			if (nq === 0) return [];
-			const dim = vectorsI8[0].length;
+			const dim = this.currentConfig.dim | 0;
 			const packed = new Int8Array(nq * dim);
-			for (let i = 0; i < nq; i++) packed.set(vectorsI8[i], i * dim); // one H2D copy for the batch
+			for (let i = 0; i < nq; i++) packed.set(this._vec(vectorsI8[i], "searchMany"), i * dim); // one H2D copy for the batch
 			return this._decode(native.searchMany(this.h, packed, nq, k | 0), nq, k | 0);
 		});
 	}

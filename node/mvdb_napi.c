@@ -49,6 +49,25 @@ static napi_value throw_last(napi_env env, mvdb_index *h)
 	napi_throw_error(env, NULL, mvdb_last_error(h));
 	return NULL;
 }
+static napi_value throw_type(napi_env env, const char *msg)
+{
+	napi_throw_type_error(env, NULL, msg);
+	return NULL;
+}
+/* nq rows of `elem`-byte elements of the handle's dim must fit in `nbytes` (nq < 0 never fits) */
+static int rows_fit(mvdb_index *h, int nq, size_t elem, size_t nbytes)
+{
+	const int dim = mvdb_get_dim(h);
+	if (nq < 0 || dim <= 0) return 0;
+	return (size_t)nq <= nbytes / elem / (size_t)dim;
+}
+/* an allow bitmap must cover every internal id: ceil(max_elements / 32) words */
+static int allow_fits(mvdb_index *h, size_t nbytes)
+{
+	int n = mvdb_get_max_elements(h);
+	if (n < 1) n = 1;
+	return nbytes / 4 >= ((size_t)n + 31) / 32;
+}
 /* typed array / Buffer -> pointer + byte length (NULL for null/undefined) */
 static void *bytes_of(napi_env env, napi_value v, size_t *nbytes)
 {
@@ -161,6 +180,8 @@ static napi_value InsertManyPacked(napi_env env, napi_callback_info info)
 		napi_throw_type_error(env, NULL, "insertManyPacked(ids: Int32Array, packed: Int8Array)");
 		return NULL;
 	}
+	if (nb_ids / 4 > 0x7fffffff || nb_vec != (nb_ids / 4) * (size_t)mvdb_get_dim(h))
+		return throw_type(env, "insertManyPacked: packed.length must equal ids.length * dim");
 	if (!mvdb_insert_many(h, ids, vec, (int)(nb_ids / 4))) return throw_last(env, h);
 	return NULL;
 }
@@ -173,6 +194,7 @@ static napi_value LoadDump(napi_env env, napi_callback_info info)
 	mvdb_index *h = get_handle(env, a[0]);
 	if (!h) return NULL;
 	const uint8_t *buf = (const uint8_t *)bytes_of(env, a[1], &nb);
+	if (!buf) return throw_type(env, "loadDump(dump: Buffer | Uint8Array)");
 	NAPI_OK(napi_get_boolean(env, mvdb_load_dump(h, buf, nb) != 0, &out));
 	return out;
 }
@@ -200,6 +222,7 @@ static napi_value SearchMany(napi_env env, napi_callback_info info)
 	if (!h) return NULL;
 	const int8_t *q = (const int8_t *)bytes_of(env, a[1], &nb);
 	int nq = get_i32(env, a[2]), k = get_i32(env, a[3]);
+	if (!q || !rows_fit(h, nq, 1, nb)) return throw_type(env, "searchMany: packed must hold nq rows of dim int8 values");
 	size_t kk = k > 0 ? (size_t)k : 1;
 	void *ids, *dist, *cnt;
 	napi_value t_ids = make_typed(env, napi_int32_array, (size_t)nq * kk, 4, &ids);
@@ -227,6 +250,7 @@ static napi_value AttachF32(napi_env env, napi_callback_info info)
 	if (!h) return NULL;
 	const float *base = (const float *)bytes_of(env, a[1], &nb);
 	int dim = get_i32(env, a[2]), resident = get_i32(env, a[3]);
+	if (dim != mvdb_get_dim(h)) return throw_type(env, "attachF32: dim differs from the index's dim");
 	if (!mvdb_attach_f32(h, base, dim > 0 ? (int64_t)(nb / 4 / (size_t)dim) : 0, resident)) return throw_last(env, h);
 	return NULL;
 }
@@ -242,6 +266,8 @@ static napi_value QueryMany(napi_env env, napi_callback_info info)
 	const float *q = (const float *)bytes_of(env, a[1], &nb);
 	int nq = get_i32(env, a[2]), topk = get_i32(env, a[3]), ef = get_i32(env, a[4]), annk = get_i32(env, a[5]);
 	const uint32_t *allow = argc > 6 ? (const uint32_t *)bytes_of(env, a[6], &nba) : NULL;
+	if (!q || !rows_fit(h, nq, 4, nb)) return throw_type(env, "queryMany: q must hold nq rows of dim float32 values");
+	if (allow && !allow_fits(h, nba)) return throw_type(env, "queryMany: allow bitmap shorter than ceil(max_elements / 32) words");
 	size_t tk = topk > 0 ? (size_t)topk : 1;
 	void *ids, *l2, *n;
 	napi_value t_ids = make_typed(env, napi_int32_array, (size_t)nq * tk, 4, &ids);
@@ -270,6 +296,7 @@ static napi_value PrepareQueries(napi_env env, napi_callback_info info)
 	if (!h) return NULL;
 	const float *q = (const float *)bytes_of(env, a[1], &nb);
 	int nq = get_i32(env, a[2]);
+	if (!q || !rows_fit(h, nq, 4, nb)) return throw_type(env, "prepareQueries: q must hold nq rows of dim float32 values");
 	void *qn, *q8;
 	napi_value t_n = make_typed(env, napi_float32_array, nb / 4, 4, &qn);
 	napi_value t_8 = make_typed(env, napi_int8_array, nb / 4, 1, &q8);

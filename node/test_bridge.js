@@ -40,12 +40,23 @@ function oneHotI8(dim, i) { const v = new Int8Array(dim); v[i % dim] = 127; retu
 	let mism = "";
 	try { await b.insertManyPacked(Int32Array.of(1, 2), new Int8Array(5), dim); } catch (e) { mism = String(e.message); }
 	assert(/length mismatch/.test(mism), "insertManyPacked length check");
+	// wrong-length inputs are errors, never out-of-bounds reads (search, searchMany, queryMany, allow bitmap)
+	for (const bad of [() => b.search(new Int8Array(dim - 1), 3), () => b.searchMany([oneHotI8(dim, 1), new Int8Array(7)], 3),
+		() => b.queryMany(new Float32Array(dim), 2, 3, 140, 360, null), () => b.queryMany(new Float32Array(dim), -1, 3, 140, 360, null),
+		() => b.insert(7, new Int8Array(dim + 1))]) {
+		let msg = "";
+		try { await bad(); } catch (e) { msg = String(e.message); }
+		assert(msg.length > 0, "a wrong-length argument must throw");
+	}
 	// fused pipeline: prep -> traversal -> rerank -> topK
 	const base = new Float32Array(N * dim); for (let i = 0; i < N; i++) base[i * dim + (i % dim)] = 1;
 	await b.attachF32(base, dim, true);
 	const q = new Float32Array(4 * dim); for (let i = 0; i < 4; i++) q[i * dim + i] = 3.5; // un-normalised
 	const r = await b.queryMany(q, 4, 3, 140, 360, null);
 	for (let i = 0; i < 4; i++) assert(r.ids[i * 3] === i && r.l2[i * 3] === 0 && r.l2[i * 3 + 1] === 2 && r.n[i] === 3, "queryMany");
+	let shortAllow = "";
+	try { await b.queryMany(q, 4, 3, 140, 360, new Uint32Array(2)); } catch (e) { shortAllow = String(e.message); }
+	assert(/allow bitmap/.test(shortAllow), "a short allow bitmap must throw");
 	b.close(); b2.close(); b3.close();
 	console.log("node bridge test passed");
 })().catch((e) => { console.error("FAILED:", e); process.exit(1); });

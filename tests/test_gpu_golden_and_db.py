@@ -213,8 +213,7 @@ def test_pipelined_batches_equal_single_stream(gpu):
     b.attachF32(base, resident=True)
     dev = torch.device("cuda", 0)
     s = ResidentSearcher(b, 200, 10, dev)
-    old = os.environ.get("MVDB_RERANK_WAVES")
-    os.environ["MVDB_RERANK_WAVES"] = "2"
+    b.setTuning(rerank_waves=2)
     try:
         batches = [torch.from_numpy(gaussian_unit(200, 384, 100 + i)).to(dev) for i in range(5)]
         outs = []
@@ -230,10 +229,8 @@ def test_pipelined_batches_equal_single_stream(gpu):
         s.drain()
         torch.cuda.synchronize(dev)
     finally:
-        if old is None:
-            os.environ.pop("MVDB_RERANK_WAVES", None)
-        else:
-            os.environ["MVDB_RERANK_WAVES"] = old
+        b.setTuning()
+    b.checkErrors()
     for q, (ids, l2, n) in zip(batches + batches + batches, outs):
         r_ids, r_l2, r_n = s.query_many(q, 140, 1200)
         torch.cuda.synchronize(dev)

@@ -169,3 +169,29 @@ def test_scan_many_large_with_gaps(gpu):
             assert np.array_equal(gc, oc)
             assert np.array_equal(gi, oi), (metric, k)
             assert np.array_equal(gv, ov), (metric, k)
+
+
+def test_scan_many_512d_bit_exact(gpu):
+    """BASELINE config 3's dimension: the 512-d instantiation of the MFMA scan (8 k-steps per row), more than one
+    256-query tile, k from 1 to the kernel's maximum, L2 and dot, against the oracle's exhaustive scan."""
+    from minivectordb_amd import HipBridge
+    n, dim = 24000, 512
+    rng = np.random.default_rng(41)
+    b8 = O.quantize_rows_i8(O.normalize_rows_f32(rng.standard_normal((n, dim), dtype=np.float32)))
+    b8[100] = b8[7]; b8[2000] = b8[7]                       # exact duplicates: ties broken by id
+    ix = O.OracleIndex(dim, 2, 4, n, seed=5)
+    ix.insert_many(np.arange(n, dtype=np.int32), b8)
+    b = HipBridge()
+    b.init(dict(dim=dim, m=2, ef=4, capacity=8, seed=1))
+    b.loadBytes(ix.save_bytes())
+    q8 = O.quantize_rows_i8(O.normalize_rows_f32(rng.standard_normal((333, dim), dtype=np.float32)))
+    q8[5] = b8[7]
+    for metric in ("l2", "dot"):
+        for k in (1, 10, 32):
+            gi, gv, gc = b.scanMany(q8, k, metric)
+            oi, ov, oc = ix.scan_many(q8, k, metric, threads=8)
+            assert np.array_equal(gc, oc)
+            assert np.array_equal(gi, oi), (metric, k)
+            assert np.array_equal(gv, ov), (metric, k)
+    with pytest.raises(Exception):
+        b.scanMany(q8[:4], 33, "l2")                         # k beyond the documented maximum is an error, not a truncation

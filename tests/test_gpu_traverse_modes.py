@@ -2,8 +2,6 @@
 on shapes chosen to reach the corners of the two-wave protocol: result heap filling up inside a
 list, candidate heap saturated (pushes dropped, hnsw.ts:500), lists of 64 neighbours (two row
 passes), M_MAX0 > 64 (one-wave kernel only), tiny graphs, heavy distance ties."""
-import os
-
 import numpy as np
 import pytest
 
@@ -41,11 +39,11 @@ def _same(b, ix, q8, k, ef):
     oi, od, oc, octr = ix.search_many(q8, k, threads=8)
     outs = {}
     for waves in ("1", "2", "3"):
-        os.environ["MVDB_TRAVERSE_WAVES"] = waves
+        b.setTuning(traverse_waves=int(waves))
         try:
             ids, dist, cnt, ctr = b.searchManyArrays(q8, k, with_counters=True)
         finally:
-            os.environ.pop("MVDB_TRAVERSE_WAVES", None)
+            b.setTuning()
         assert np.array_equal(cnt, oc), f"waves={waves} k={k} ef={ef}: counts differ"
         assert np.array_equal(ids, oi), f"waves={waves} k={k} ef={ef}: ids differ"
         assert np.array_equal(dist.view(np.uint32), od.view(np.uint32)), f"waves={waves}: dists differ"
@@ -111,11 +109,51 @@ def test_fused_query_path_set_only_output(gpu):
         ids, dist, cnt, _ = ix.search_many(qi, ann_k, threads=8)
         oi, ol, on = O.rerank_many(qf, base, ids, cnt, ann_k, 10, bitmap, 8)
         for waves in ("1", "2", "3"):
-            os.environ["MVDB_TRAVERSE_WAVES"] = waves
+            b.setTuning(traverse_waves=int(waves))
             try:
                 gi, gl, gn = b.queryMany(q, 10, ef, ann_k, allow_bitmap=bitmap)
             finally:
-                os.environ.pop("MVDB_TRAVERSE_WAVES", None)
+                b.setTuning()
             assert np.array_equal(gn, on), (waves, ef, ann_k)
             assert np.array_equal(gi, oi), (waves, ef, ann_k)
             assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64)), (waves, ef, ann_k)
+
+
+def test_aborted_query_is_reported_not_returned_empty(gpu):
+    """A traversal that gives up on a query (bounded waits of the wave protocol; forced here through
+    mvdb_debug_inject_abort) must fail the host calls and stay visible on the `_dev` path: n = -1 for that
+    query after the rerank and mvdb_check_errors() == 0 -- never "0 results, status ok"."""
+    import torch
+    from minivectordb_amd import MvdbError
+    from minivectordb_amd.pipeline import ResidentSearcher
+    from tests._data import bridge_from_dump, built_index, oracle_from_dump
+    dump, base, b8 = built_index(4000, 384, "balanced")
+    b = bridge_from_dump(dump, 384, "balanced")
+    ix = oracle_from_dump(dump, 384, "balanced")
+    b.attachF32(base)
+    q = np.random.default_rng(5).standard_normal((40, 384)).astype(np.float32)
+    qi = O.quantize_rows_i8(O.normalize_rows_f32(q))
+    oi, ol, on, _, _, _ = O.search_many_db(ix, q, base, 10, "balanced", threads=8)
+    dev = torch.device("cuda", 0)
+    s = ResidentSearcher(b, 40, 10, dev)
+    q_dev = torch.from_numpy(q).to(dev)
+    for waves in (1, 2, 3):
+        b.setTuning(traverse_waves=waves)
+        b._L.mvdb_debug_inject_abort(b.handle, 17)
+        with pytest.raises(MvdbError, match="aborted"):
+            b.searchManyArrays(qi, 50)
+        with pytest.raises(MvdbError, match="aborted"):
+            b.queryMany(q, 10, 140, 1200)
+        ids, l2, n = s.query_many(q_dev, 140, 1200)          # device-pointer path: nothing synchronises inside
+        torch.cuda.synchronize(dev)
+        n_h = n.cpu().numpy()
+        assert n_h[17] == -1 and np.array_equal(np.delete(n_h, 17), np.delete(on, 17)), waves
+        assert np.array_equal(np.delete(ids.cpu().numpy(), 17, 0), np.delete(oi, 17, 0))
+        assert s.ctr[17, 3].item() == -1
+        with pytest.raises(MvdbError, match="aborted"):
+            s.check()
+        s.check()                                            # the error word was cleared by the failed check
+        b._L.mvdb_debug_inject_abort(b.handle, -1)
+        gi, gl, gn = b.queryMany(q, 10, 140, 1200)           # and the handle keeps working
+        assert np.array_equal(gn, on) and np.array_equal(gi, oi) and np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
+    b.setTuning()

@@ -123,3 +123,101 @@ def test_compute_without_gpu_fails_loudly():
     b.loadBytes(dump)
     with pytest.raises(MvdbError):
         b.searchManyArrays(b8[:2], 10)
+
+
+def test_product_loader_accepts_and_rejects_exactly_like_load_index():
+    """The corruption matrix of tests/test_oracle_cross.py (and more) against the PRODUCT's loader
+    (HostGraph::load through HipBridge.loadBytes) beside the oracle's load_index (hnsw.ts:1129-1249):
+    same accept/reject verdict for every mutation, the same fresh empty index after a reject
+    (wasm-bridge.ts:463-466), and byte-identical re-serialisation after an accept (neighbour ids out of
+    range are rewritten to -1 by both, :1222-1229)."""
+    import struct
+    from tests import _dump as D
+    dump, base, b8 = built_index(300, 16, "fast")
+    p = resolve_preset("fast")
+    recs = D.walk(dump)
+    r0, r5 = recs[0], recs[5]
+
+    def both(buf, tag):
+        buf = bytes(buf)
+        ix = O.OracleIndex(16, p["m"], p["ef_construction"], 7, seed=1)
+        a = ix.load_bytes(buf)
+        b = HipBridge()
+        b.init(dict(dim=16, m=p["m"], ef=p["ef_construction"], capacity=7, seed=1))
+        try:
+            b.loadBytes(buf)
+            ok = True
+        except MvdbError:
+            ok = False
+        assert ok == a, f"{tag}: product {'accepts' if ok else 'rejects'}, load_index {'accepts' if a else 'rejects'}"
+        if a:
+            assert b.saveBytes() == ix.save_bytes(), f"{tag}: re-serialised dumps differ"
+            assert b.getResultsCap() == ix.get_results_cap(), tag
+        else:
+            assert b.getMaxElements() == 7 and b.elementCount() == 0, tag
+        ix.close(); b.close()
+        return a
+
+    def hdr(field, value):
+        bad = bytearray(dump)
+        struct.pack_into("<i", bad, 4 * field, value)
+        return bad
+
+    assert both(dump, "clean")
+    assert both(dump + b"\x00" * 9, "trailing bytes")                   # nothing reads past the last record
+    for cut in (0, 10, 40, 47, 48, 49, 56, 60, r0[3][0][1] + 2, len(dump) // 2, len(dump) - 1):
+        assert not both(dump[:cut], f"cut at {cut}")
+    bad = bytearray(dump); bad[0] ^= 1; assert not both(bad, "magic")
+    for field, values, name in [(1, (2, 4, 0), "version"), (2, (32, 0), "dim"), (3, (p["m"] + 1,), "m"),
+                                (4, (2 * p["m"] + 1,), "m_max0"), (5, (p["ef_construction"] + 1,), "ef_construction"),
+                                (6, (3, 5), "max_layers"), (7, (0, -5), "max_elements"), (8, (-1, 10**6), "present"),
+                                (9, (-2, 10**6, 300), "entry"), (10, (-2, 4, 99), "max_level")]:
+        for v in values:
+            assert not both(hdr(field, v), f"{name}={v}")
+    assert not both(hdr(9, -1), "entry -1 with present > 0")            # :1173
+    both(hdr(7, 299), "max_elements one short of the highest id")        # record id out of range -> reject
+    both(hdr(7, 5000), "max_elements larger than the data")              # accepted: a larger, sparse index
+    both(hdr(8, 299), "present one short")                               # accepted: the last record is never read
+    both(hdr(8, 301), "present one too many")                            # runs off the end -> reject
+    both(hdr(10, 0), "max_level lower than the nodes' levels")           # header is trusted (:1170 range check only)
+    for v in (0, -7, 1, 4096, 10**6):
+        assert both(hdr(11, v), f"results_cap={v}")                      # :1176-1179 (<= 0 keeps the current cap)
+    # record level
+    rec_off = r5[2] - 8
+    for v, name in [(-1, "id -1"), (300, "id == max_elements"), (10**6, "id huge")]:
+        bad = bytearray(dump); D.put_i32(bad, rec_off, v); assert not both(bad, name)
+    bad = bytearray(dump); D.put_i32(bad, rec_off, r0[0]); both(bad, "repeated id")
+    for v in (-1, 4, 9):
+        bad = bytearray(dump); D.put_i32(bad, rec_off + 4, v); assert not both(bad, f"level={v}")
+    for l, c_off, i_off, cap in r5[3]:
+        for v in (-1, cap + 1, 999):
+            bad = bytearray(dump); D.put_i32(bad, c_off, v); assert not both(bad, f"layer {l} count={v}")
+        bad = bytearray(dump); D.put_i32(bad, c_off, 0); assert both(bad, f"layer {l} count=0")
+        for v in (-2, -10**6, 300, 10**9):                               # sanitised to -1 by both
+            bad = bytearray(dump); D.put_i32(bad, i_off, v); assert both(bad, f"layer {l} neighbour={v}")
+        bad = bytearray(dump); D.put_i32(bad, i_off, r5[0]); assert both(bad, f"layer {l} self edge")
+    # the entry point's own record missing (present shrunk so that it is never read) -> entry must exist (:1241)
+    entry = D.header(dump)[9]
+    pos = [i for i, r in enumerate(recs) if r[0] == entry][0]
+    bad = hdr(8, pos)
+    assert not both(bad[:recs[pos][2] - 8] if pos else bad, "entry record absent")
+
+
+def test_python_bridge_rejects_wrong_shapes():
+    """row lengths and the allow bitmap are checked before any pointer reaches the C ABI."""
+    dump, base, b8 = built_index(300, 16, "fast")
+    p = resolve_preset("fast")
+    b = HipBridge()
+    b.init(dict(dim=16, m=p["m"], ef=p["ef_construction"], capacity=7, seed=1))
+    b.loadBytes(dump)
+    for call in (lambda: b.searchManyArrays(np.zeros((3, 15), np.int8), 5),
+                 lambda: b.search(np.zeros(17, np.int8), 5),
+                 lambda: b.queryMany(np.zeros((2, 12), np.float32), 5, 50, 50),
+                 lambda: b.queryMany(np.zeros((2, 16), np.float32), 5, 50, 50, allow_bitmap=np.zeros(3, np.uint32)),
+                 lambda: b.rerankMany(np.zeros((2, 16), np.float32), np.zeros((3, 8), np.int32), np.zeros(2, np.int32), 8, 5),
+                 lambda: b.prepareQueries(np.zeros(33, np.float32)),
+                 lambda: b.attachF32(np.zeros((4, 8), np.float32)),
+                 lambda: b.distMany(np.zeros((2, 16), np.int8), np.zeros((3, 4), np.int32)),
+                 lambda: b.setTuning(traverse_waves=7)):
+        with pytest.raises(MvdbError):
+            call()

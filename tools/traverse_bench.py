@@ -2,7 +2,7 @@
 
     python tools/traverse_bench.py [rows] [dim] [nq] [ef] [threads]
 
-Builds the index once (buildParallel), runs the batch under MVDB_TRAVERSE_WAVES=1 and =2,
+Builds the index once (buildParallel), runs the batch with 1, 2 and 3 waves per query (setTuning),
 requires identical output, prints per-launch kernel times from the engine's stage timers.
 """
 import ctypes as C
@@ -64,7 +64,7 @@ def main():
     out = {"rows": rows, "dim": dim, "nq": nq, "ef": ef, "build_s": round(build_s, 1)}
     results = {}
     for mode in ("1", "2", "3"):
-        os.environ["MVDB_TRAVERSE_WAVES"] = mode
+        b.setTuning(traverse_waves=int(mode))
         for _ in range(2):
             r = b.searchManyArrays(q8, ef, with_counters=True)
         stats(1)
