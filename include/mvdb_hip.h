@@ -132,6 +132,19 @@ int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out
                      int32_t *out_count, mvdb_query_counters *ctr);
 int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids,
                          float *d_out_dist, int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream);
+/* Upload the index to the device now (every compute entry point otherwise does it lazily after a
+ * change).  Also the set-up call of mvdb_search_many_dev_noalloc.  No reference counterpart. */
+int mvdb_upload(mvdb_index *h);
+/* NO COUNTERPART IN THE REFERENCE.  mvdb_search_many_dev for callers that cannot allocate: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels, same outputs; the
+ * per-query visited bitmaps live in a static 8 MiB device array of the library (one copy per GPU, held
+ * until the process ends) instead of hipMalloc'ed scratch, so the call makes no hipMalloc, hipFree or
+ * event creation.  Requirements: mvdb_upload(h) since the last change of the index (else status 0);
+ * nq * ceil(max_elements / 32) * 4 bytes <= 8 MiB (64 queries at 1 M nodes; else status 0 with a clear
+ * text); device ordinal < 16.  Every call on one GPU shares that GPU's array: calls that overlap on one
+ * GPU (any handle, any stream) race -- serialise them. */
+int mvdb_search_many_dev_noalloc(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids,
+                                 float *d_out_dist, int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream);
 /* WasmBridge.search (wasm-bridge.ts:301-321): one query, returns the count */
 int mvdb_search(mvdb_index *h, const int8_t *q, int k, int32_t *out_ids, float *out_dist);
 

@@ -53,6 +53,8 @@ SYMBOLS = [
     ("mvdb_prepare_queries_dev", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
     ("mvdb_search_many", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_search_many_dev", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mvdb_upload", _i, [_vp]),
+    ("mvdb_search_many_dev_noalloc", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mvdb_search", _i, [_vp, _vp, _i, _vp, _vp]),
     ("mvdb_rerank_many", _i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     ("mvdb_rerank_many_dev", _i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -180,6 +180,16 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 	return true;
 }
 
+// --------------------------------------------------------------------------- no-allocation scratch
+// mvdb_search_many_dev_noalloc keeps its visited bitmaps here instead of in hipMalloc'ed memory.
+// `scratch` is a host-side stand-in, not a device address: host code only ever uses the per-device
+// pointer hipGetSymbolAddress returned (resolve_scratch, with that device current), as the kernel
+// argument and for hipMemsetAsync.  Every GPU the library runs on holds its own 8 MiB copy.
+constexpr size_t kNoAllocScratchBytes = (size_t)8 << 20;
+constexpr int kMaxDevices = 16;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+static void *g_scratch_ptr[kMaxDevices];
+
 // --------------------------------------------------------------------------- handle
 constexpr int kStreamSets = 4;
 
@@ -259,9 +269,22 @@ void bridge_reinit(mvdb_index *h)
 	h->g.init(gc, h->cfg.capacity);
 }
 
+// once per device, with that device current: where this GPU keeps its copy of `scratch`
+int resolve_scratch(mvdb_index *h)
+{
+	const int d = h->device;
+	if (d < 0 || d >= kMaxDevices) return 1;  // no scratch pointer there: the no-allocation entry point refuses such a device
+	if (g_scratch_ptr[d]) return 1;
+	void *p = nullptr;
+	HIP_OK(h, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+	g_scratch_ptr[d] = p;
+	return 1;
+}
+
 int ensure_device(mvdb_index *h)
 {
 	HIP_OK(h, hipSetDevice(h->device));
+	if (!resolve_scratch(h)) return 0;
 	if (!h->err_host) {
 		HIP_OK(h, hipHostMalloc(reinterpret_cast<void **>(&h->err_host), 64, hipHostMallocMapped));
 		*h->err_host = 0;
@@ -576,6 +599,27 @@ int mvdb_prepare_queries(mvdb_index *h, const float *q_in, int nq, float *q_norm
 }  // extern "C"
 
 namespace {
+// search(): the effective-ef rule and search_layer's candidate capacity
+void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
+{
+	int ef = h->ef_search;  // hnsw.ts:1006-1011
+	if (ef < k) ef = k;
+	if (ef > kMaxEf) {
+		ef = kMaxEf;
+		h->g.ef_clamped = true;
+	}
+	int cand_cap = ef * 2 + 32;  // hnsw.ts:443-445
+	if (cand_cap > kMaxEf) cand_cap = kMaxEf;
+	if (cand_cap < ef) cand_cap = ef;
+	a.ix = h->dev.view;
+	a.k = k;
+	a.ef = ef;
+	a.cand_cap = cand_cap;
+	a.results_cap = h->g.results_cap;
+	a.set_only = set_only ? 1 : 0;
+	a.vis_words = ((size_t)h->g.max_elements + 31) / 32;
+}
+
 mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
 {
 	for (auto &c : h->ss)
@@ -610,24 +654,8 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		if (d_ctr) HIP_OK(h, hipMemsetAsync(d_ctr, 0, (size_t)nq * sizeof(mvdb_query_counters), s));
 		return 1;
 	}
-	int ef = h->ef_search;  // hnsw.ts:1006-1011
-	if (ef < k) ef = k;
-	if (ef > kMaxEf) {
-		ef = kMaxEf;
-		h->g.ef_clamped = true;
-	}
-	int cand_cap = ef * 2 + 32;  // hnsw.ts:443-445
-	if (cand_cap > kMaxEf) cand_cap = kMaxEf;
-	if (cand_cap < ef) cand_cap = ef;
-
 	TraverseArgs a;
-	a.ix = h->dev.view;
-	a.k = k;
-	a.ef = ef;
-	a.cand_cap = cand_cap;
-	a.results_cap = g.results_cap;
-	a.set_only = set_only ? 1 : 0;
-	a.vis_words = ((size_t)g.max_elements + 31) / 32;
+	traverse_params(h, k, a, set_only);
 	// visited bitmaps: bounded scratch, queries are processed in slabs
 	const size_t slab_bytes_max = (size_t)2 << 30;
 	int slab = (int)std::min<size_t>((size_t)nq, std::max<size_t>(1, slab_bytes_max / (a.vis_words * 4)));
@@ -697,6 +725,55 @@ int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out
 	}
 	if (ctr) HIP_OK(h, hipMemcpy(ctr, d_ctr, (size_t)nq * sizeof(mvdb_query_counters), hipMemcpyDeviceToHost));
 	return 1;
+}
+
+int mvdb_upload(mvdb_index *h) { return ensure_uploaded(h); }
+
+// The same launch as mvdb_search_many_dev with the visited bitmaps in the library's static device array:
+// no hipMalloc/hipFree/event creation on this path.  Everything that allocates (device mirror, error word,
+// kernel attributes' first set-up is not an allocation) must have happened in mvdb_upload().
+int mvdb_search_many_dev_noalloc(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids,
+                                 float *d_out_dist, int32_t *d_out_count, mvdb_query_counters *d_ctr, void *stream)
+{
+	if (nq <= 0) return 1;
+	if (!h->err_host || h->dev.built_version != h->g.version) {
+		h->set_error("mvdb_search_many_dev_noalloc: index not resident on the device; call mvdb_upload() after the last change");
+		return 0;
+	}
+	const int d = h->device;
+	if (d < 0 || d >= kMaxDevices || !g_scratch_ptr[d]) {
+		h->set_error("mvdb_search_many_dev_noalloc: no scratch pointer for this device (device ordinal >= 16?)");
+		return 0;
+	}
+	HIP_OK(h, hipSetDevice(d));
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const HostGraph &g = h->g;
+	if (g.entry_point == -1 || g.max_elements <= 0 || k <= 0 || !g.present(g.entry_point)) {  // hnsw.ts:961-967
+		HIP_OK(h, hipMemsetAsync(d_out_count, 0, (size_t)nq * 4, s));
+		if (d_ctr) HIP_OK(h, hipMemsetAsync(d_ctr, 0, (size_t)nq * sizeof(mvdb_query_counters), s));
+		return 1;
+	}
+	TraverseArgs a;
+	traverse_params(h, k, a, false);
+	const size_t need = (size_t)nq * a.vis_words * 4;
+	if (need > kNoAllocScratchBytes) {
+		h->set_error("mvdb_search_many_dev_noalloc: nq * ceil(max_elements / 32) * 4 bytes of visited bitmaps exceed the "
+		             "8 MiB static scratch (e.g. 64 queries at 1 M nodes); use mvdb_search_many_dev");
+		return 0;
+	}
+	uint32_t *vis = static_cast<uint32_t *>(g_scratch_ptr[d]);  // never the array's name: that is not a device address
+	HIP_OK(h, hipMemsetAsync(vis, 0, need, s));                 // the array keeps the last call's bits
+	a.q = d_q;
+	a.nq = nq;
+	a.visited = vis;
+	a.out_ids = d_out_ids;
+	a.out_dist = d_out_dist;
+	a.out_count = d_out_count;
+	a.ctr = d_ctr;
+	a.prof = nullptr;
+	a.err = h->err_dev;
+	a.inject_abort_q = h->inject_abort_q < nq ? h->inject_abort_q : -1;
+	return launch_traverse(h, a, s);
 }
 
 int mvdb_search(mvdb_index *h, const int8_t *q, int k, int32_t *out_ids, float *out_dist)
