@@ -108,6 +108,15 @@ int mvdb_update_vector(mvdb_index *h, int id, const int8_t *vec);
 /* Benchmark-data builder: the same insert algorithm run by `threads` workers
  * (NOT the reference's sequential order).  ids 0..n-1, index must be empty. */
 int mvdb_build_parallel(mvdb_index *h, const int8_t *packed, int n, int threads);
+/* Bulk builder on the GPU: the reference's per-insert algorithm (search_layer in build
+ * mode hnsw.ts:423-523, select_neighbors_heuristic :526-574, add_connection / remove_connection :593-678)
+ * applied to a block of new nodes at a time; nodes of one block do not see each other, blocks are at most
+ * 1/32 of the nodes already linked (and <= max_block, <= 0 = 32768).  ids 0..n-1, index must be empty,
+ * M_MAX0 <= 64.  Same level assignment as a sequential build with the handle's seed; the edge set is not
+ * the sequential one.  The result is an ordinary host graph: mvdb_save_dump writes a V3 file the reference
+ * loads.  stats_out: NULL or 8 doubles {seconds, host-prefix seconds, distance evaluations, nodes expanded,
+ * evictions, removed back edges, passes, nodes linked on the host}. */
+int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, double *stats_out);
 
 /* ---- float32 store (vectors.f32.bin, src/mini-vector-db.ts:1013-1036) ---- */
 /* Upload `rows` x dim f32 rows (row id at byte id*dim*4) for the rerank stage.

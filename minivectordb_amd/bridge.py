@@ -190,6 +190,17 @@ class HipBridge:
         with self._lock:
             self._check(self._L.mvdb_build_parallel(self.handle, _ptr(packed), n, int(threads)))
 
+    def buildGpu(self, packed, max_block: int = 0) -> dict:
+        """Bulk builder on the GPU (not in the reference; mvdb_build_gpu): blocks of new nodes linked with
+        the reference's per-insert algorithm.  ids 0..n-1 into an empty index.  Returns the build's counters."""
+        packed = self._rows(packed, np.int8, "buildGpu")
+        st = np.zeros(8, np.float64)
+        with self._lock:
+            self._check(self._L.mvdb_build_gpu(self.handle, _ptr(packed), packed.shape[0], int(max_block), _ptr(st)))
+        keys = ("seconds", "host_prefix_seconds", "n_dist", "n_expanded", "evictions", "removed_back_edges", "passes",
+                "host_linked")
+        return dict(zip(keys, st.tolist()))
+
     # ---- search ---------------------------------------------------------------
     def searchManyArrays(self, vectorsI8, k: int, with_counters: bool = False):
         q = self._rows(vectorsI8, np.int8, "searchMany")

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 #include "scan.hip.hpp"
 #include "traverse.hip.hpp"
 #include "traverse_duo.hip.hpp"
+#include "build_gpu.hip.hpp"
 
 using namespace mvdb;
 
@@ -529,6 +531,191 @@ int mvdb_build_parallel(mvdb_index *h, const int8_t *packed, int n, int threads)
 		return 0;
 	}
 	h->g.build_parallel(packed, n, threads);
+	return 1;
+}
+
+}  // extern "C"
+
+namespace {
+template <int J, bool FULL>
+int launch_build_link_t(mvdb_index *h, const BuildArgs &a, size_t lds)
+{
+	static int mark[16] = {0};
+	if (!set_max_lds(h, reinterpret_cast<const void *>(&build_link_kernel<J, FULL>), mark, lds)) return 0;
+	hipLaunchKernelGGL((build_link_kernel<J, FULL>), dim3(a.count), dim3(64), lds, nullptr, a);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+template <int J, bool FULL>
+int launch_build_apply_t(mvdb_index *h, const BuildArgs &a, int n_targets)
+{
+	hipLaunchKernelGGL((build_apply_kernel<J, FULL>), dim3(n_targets), dim3(64), 0, nullptr, a, n_targets);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+// which = 0: build_link_kernel over a.count new nodes; which = 1: build_apply_kernel over n_targets
+int launch_build(mvdb_index *h, const BuildArgs &a, int which, size_t lds, int n_targets)
+{
+	const int stride = a.ix.row_stride;
+	const int J = (stride + 127) / 128;
+	const bool full = stride == J * 128;
+#define MVDB_B(JJ)                                                                                       \
+	if (J <= JJ) {                                                                                       \
+		if (full && J == JJ)                                                                             \
+			return which == 0 ? launch_build_link_t<JJ, true>(h, a, lds) : launch_build_apply_t<JJ, true>(h, a, n_targets); \
+		return which == 0 ? launch_build_link_t<JJ, false>(h, a, lds) : launch_build_apply_t<JJ, false>(h, a, n_targets);   \
+	}
+	MVDB_B(1)
+	MVDB_B(2)
+	MVDB_B(3)
+	MVDB_B(4)
+	MVDB_B(6)
+	MVDB_B(8)
+#undef MVDB_B
+	h->set_error("dim > 1024 is not supported by the GPU builder");
+	return 0;
+}
+}  // namespace
+
+extern "C" {
+
+// Batched GPU build (build_gpu.hip.hpp).  ids 0..n-1 into an empty index; `max_block` caps the block of
+// nodes linked per pass (<= 0: 32768).  stats_out (8 doubles, may be NULL): seconds total, seconds of the
+// sequential host prefix, distance evaluations, nodes expanded, evictions, reverse-edge removals, passes,
+// nodes linked on the host.
+int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, double *stats_out)
+{
+	using clk = std::chrono::steady_clock;
+	if (h->g.element_count != 0) {
+		h->set_error("mvdb_build_gpu needs an empty index");
+		return 0;
+	}
+	if (!packed || n <= 0) return 1;
+	if (!ensure_device(h)) return 0;
+	HostGraph &g = h->g;
+	n = std::min(n, g.max_elements);
+	const int dim = g.cfg.dim, m = g.cfg.m, m0 = g.cfg.m0();
+	if (m0 > kBuildMaxM0) {
+		h->set_error("mvdb_build_gpu: M_MAX0 > 64 is not supported (use mvdb_build_parallel)");
+		return 0;
+	}
+	if (max_block <= 0) max_block = 32768;
+	const auto t0 = clk::now();
+	const int linked0 = g.bulk_begin(packed, n, std::min(n, 2048));
+	const double prefix_s = std::chrono::duration<double>(clk::now() - t0).count();
+	double st[8] = {0, prefix_s, 0, 0, 0, 0, 0, (double)linked0};
+	if (linked0 < n) {
+		h->dev.release();  // the search mirror is stale anyway; its memory is needed at 10 M+
+		int ef = g.cfg.ef_construction;
+		if (ef > kMaxEf) ef = kMaxEf;
+		const int cand_cap = std::max(std::min(2 * ef + 32, kMaxEf), ef);
+		const int stride = (dim + 15) & ~15;
+		const int slots = m0 + (kMaxLayers - 1) * m;
+		max_block = std::min(max_block, n);
+		const size_t n_slots_max = (size_t)max_block * slots;
+		DevBuf b_vec, b_level, b_adj0, b_cnt0, b_off, b_upper, b_head, b_req, b_rem, b_next, b_tlist, b_misc;
+		int8_t *d_vec = static_cast<int8_t *>(b_vec.need((size_t)n * stride));
+		int8_t *d_level = static_cast<int8_t *>(b_level.need((size_t)n));
+		int32_t *d_adj0 = static_cast<int32_t *>(b_adj0.need((size_t)n * m0 * 4));
+		int32_t *d_cnt0 = static_cast<int32_t *>(b_cnt0.need((size_t)n * 4));
+		int64_t *d_off = static_cast<int64_t *>(b_off.need((size_t)n * 8));
+		int32_t *d_upper = static_cast<int32_t *>(b_upper.need(std::max<size_t>(g.upper.size() * 4, 256)));
+		int32_t *d_head = static_cast<int32_t *>(b_head.need((size_t)n * 4));
+		int4 *d_req = static_cast<int4 *>(b_req.need(n_slots_max * 16));
+		int4 *d_rem = static_cast<int4 *>(b_rem.need(n_slots_max * 16));
+		int32_t *d_next = static_cast<int32_t *>(b_next.need(n_slots_max * 4));
+		int32_t *d_tlist = static_cast<int32_t *>(b_tlist.need(n_slots_max * 4));
+		unsigned char *d_misc = static_cast<unsigned char *>(b_misc.need(256));
+		if (!d_vec || !d_level || !d_adj0 || !d_cnt0 || !d_off || !d_upper || !d_head || !d_req || !d_rem || !d_next ||
+		    !d_tlist || !d_misc) {
+			h->set_error("out of device memory (GPU builder)");
+			return 0;
+		}
+		if (stride == dim) HIP_OK(h, hipMemcpy(d_vec, g.vec.data(), (size_t)n * dim, hipMemcpyHostToDevice));
+		else {
+			HIP_OK(h, hipMemset(d_vec, 0, (size_t)n * stride));
+			HIP_OK(h, hipMemcpy2D(d_vec, stride, g.vec.data(), dim, dim, n, hipMemcpyHostToDevice));
+		}
+		HIP_OK(h, hipMemcpy(d_level, g.level.data(), (size_t)n, hipMemcpyHostToDevice));
+		HIP_OK(h, hipMemcpy(d_adj0, g.adj0.data(), (size_t)n * m0 * 4, hipMemcpyHostToDevice));
+		HIP_OK(h, hipMemcpy(d_cnt0, g.cnt0.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+		HIP_OK(h, hipMemcpy(d_off, g.upper_off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+		if (!g.upper.empty()) HIP_OK(h, hipMemcpy(d_upper, g.upper.data(), g.upper.size() * 4, hipMemcpyHostToDevice));
+		HIP_OK(h, hipMemset(d_head, 0xff, (size_t)n * 4));
+		HIP_OK(h, hipMemset(d_misc, 0, 256));
+
+		BuildArgs a;
+		a.ix = DevIndexView{};
+		a.ix.vec = d_vec;
+		a.ix.dim = dim;
+		a.ix.row_stride = stride;
+		a.ix.m = m;
+		a.ix.m0 = m0;
+		a.ix.max_elements = n;
+		a.ix.entry = g.entry_point;
+		a.ix.max_level = g.max_level;
+		a.level = d_level;
+		a.adj0 = d_adj0;
+		a.cnt0 = d_cnt0;
+		a.upper_off = d_off;
+		a.upper = d_upper;
+		a.ef = ef;
+		a.cand_cap = cand_cap;
+		a.bloom_log2 = ef <= 400 ? 16 : (ef <= 1200 ? 17 : 18);
+		a.slots = slots;
+		a.req = d_req;
+		a.rem = d_rem;
+		a.next = d_next;
+		a.head = d_head;
+		a.tlist = d_tlist;
+		a.tcount = reinterpret_cast<int32_t *>(d_misc);
+		a.stats = reinterpret_cast<unsigned long long *>(d_misc + 64);
+		const size_t lds = build_link_lds_bytes(ef, cand_cap, a.bloom_log2);
+		if (lds > 160 * 1024) {
+			h->set_error("mvdb_build_gpu: ef_construction too large for the LDS heaps");
+			return 0;
+		}
+		int passes = 0;
+		for (int linked = linked0; linked < n;) {
+			const int block = std::min(n - linked, std::max(64, std::min(max_block, linked / 32)));
+			a.first = linked;
+			a.count = block;
+			const int n_slots = block * slots;
+			if (!launch_build(h, a, 0, lds, 0)) return 0;
+			for (int pass = 0; pass < 2; pass++) {  // 0: reverse adds, 1: removals of the evicted back edges
+				HIP_OK(h, hipMemsetAsync(a.tcount, 0, 4, nullptr));
+				hipLaunchKernelGGL(build_group_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, nullptr,
+				                   pass == 0 ? a.req : a.rem, n_slots, a.next, a.head, a.tlist, a.tcount,
+				                   pass == 0 ? a.rem : static_cast<int4 *>(nullptr));
+				HIP_OK(h, hipGetLastError());
+				int n_targets = 0;
+				HIP_OK(h, hipMemcpy(&n_targets, a.tcount, 4, hipMemcpyDeviceToHost));
+				if (n_targets <= 0) continue;
+				if (pass == 0) {
+					if (!launch_build(h, a, 1, 0, n_targets)) return 0;
+				} else {
+					hipLaunchKernelGGL(build_remove_kernel, dim3(n_targets), dim3(64), 0, nullptr, a, n_targets);
+					HIP_OK(h, hipGetLastError());
+				}
+			}
+			linked += block;
+			passes++;
+		}
+		HIP_OK(h, hipDeviceSynchronize());
+		HIP_OK(h, hipMemcpy(g.adj0.data(), d_adj0, (size_t)n * m0 * 4, hipMemcpyDeviceToHost));
+		HIP_OK(h, hipMemcpy(g.cnt0.data(), d_cnt0, (size_t)n * 4, hipMemcpyDeviceToHost));
+		if (!g.upper.empty()) HIP_OK(h, hipMemcpy(g.upper.data(), d_upper, g.upper.size() * 4, hipMemcpyDeviceToHost));
+		unsigned long long dst[4] = {0, 0, 0, 0};
+		HIP_OK(h, hipMemcpy(dst, a.stats, sizeof(dst), hipMemcpyDeviceToHost));
+		st[2] = (double)dst[0];
+		st[3] = (double)dst[1];
+		st[4] = (double)dst[2];
+		st[5] = (double)dst[3];
+		st[6] = passes;
+	}
+	g.bulk_end(n);
+	st[0] = std::chrono::duration<double>(clk::now() - t0).count();
+	if (stats_out) std::memcpy(stats_out, st, sizeof(st));
 	return 1;
 }
 

@@ -612,6 +612,40 @@ void HostGraph::update_and_reconnect(int id, const int8_t *v)
 	}
 }
 
+int HostGraph::bulk_begin(const int8_t *packed, int n, int prefix)
+{
+	n = std::min(n, max_elements);
+	if (n <= 0) return 0;
+	version++;
+	std::memcpy(vec.data(), packed, (size_t)n * cfg.dim);
+	std::vector<int8_t> lv((size_t)n);
+	size_t upper_total = 0;
+	for (int i = 0; i < n; i++) {
+		lv[i] = (int8_t)random_level();
+		upper_total += (size_t)lv[i] * (1 + (size_t)cfg.m);
+	}
+	upper.reserve(upper.size() + upper_total);
+	for (int i = 0; i < n; i++) create_node(i, lv[i]);
+	entry_point = 0;
+	max_level = lv[0];
+	int k = 1;
+	for (; k < n && (k < prefix || max_level < kMaxLayers - 1); k++) {
+		link_new_node(k, lv[k], *main_, false, entry_point, max_level);
+		if (lv[k] > max_level) {  // insert :829-832
+			max_level = lv[k];
+			entry_point = k;
+		}
+	}
+	element_count = k;
+	return k;
+}
+
+void HostGraph::bulk_end(int n)
+{
+	element_count = std::min(n, max_elements);
+	version++;
+}
+
 // Multi-threaded builder.  Levels come from the same RNG stream in id order, so
 // the level assignment equals a sequential build; edge sets differ run to run.
 void HostGraph::build_parallel(const int8_t *packed, int n, int threads)

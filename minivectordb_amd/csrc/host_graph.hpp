@@ -83,6 +83,12 @@ public:
 	void insert(int id, const int8_t *v);              // hnsw.ts:719-834 (upsert)
 	void update_vector(int id, const int8_t *v);       // hnsw.ts:837-841
 	void build_parallel(const int8_t *packed, int n, int threads);
+	// Shared prologue of the bulk builders: rows copied, levels drawn from the RNG stream in id order (the
+	// level assignment of a sequential build), every node block created, then ids [0, k) linked one by
+	// one with the reference algorithm, k >= prefix and large enough for max_level to have reached its
+	// cap (so that entry point and max_level are final).  Returns k.  bulk_end() publishes n nodes.
+	int bulk_begin(const int8_t *packed, int n, int prefix);
+	void bulk_end(int n);
 
 private:
 	std::unique_ptr<BuildScratch> main_;
