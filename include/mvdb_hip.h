@@ -208,6 +208,14 @@ int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2,
                         int parts, int nq, int topk, int32_t *d_out_ids, double *d_out_l2,
                         int32_t *d_out_n, void *stream);
 
+/* The same merge over PACKED per-shard blocks, the unit of the one all-gather per batch: block =
+ * {l2 f64[nq][topk] | ids i32[nq][topk] | n i32[nq]} padded to a multiple of 8 bytes, mvdb_topk_block_bytes(nq, topk)
+ * bytes, `parts` blocks back to back (what all_gather_into_tensor produces).  A block whose n[q] is -1 (an
+ * aborted query on that shard) makes the merged n[q] -1. */
+size_t mvdb_topk_block_bytes(int nq, int topk);
+int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, int nq, int topk, int32_t *d_out_ids,
+                               double *d_out_l2, int32_t *d_out_n, void *stream);
+
 /* ---- engine state beyond the WASM surface ---------------------------------- */
 /* Kernel variants of the timed path (handle state, read at launch): traverse_waves
  * 0 = default (3 waves per query when M_MAX0 <= 64), 1/2/3 force a variant (all

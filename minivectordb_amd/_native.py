@@ -68,6 +68,8 @@ SYMBOLS = [
     ("mvdb_scan_many", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     ("mvdb_scan_many_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_merge_topk_dev", _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("mvdb_topk_block_bytes", _sz, [_i, _i]),
+    ("mvdb_merge_topk_packed_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_set_tuning", _i, [_vp, _i, _i]),
     ("mvdb_check_errors", _i, [_vp]),
     ("mvdb_debug_inject_abort", None, [_vp, _i]),

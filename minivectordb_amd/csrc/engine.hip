@@ -1285,13 +1285,40 @@ int mvdb_merge_topk_dev(mvdb_index *h, const int32_t *d_ids, const double *d_l2,
 {
 	if (!ensure_device(h)) return 0;
 	if (nq <= 0) return 1;
-	if (parts > 64 || parts < 1) {
-		h->set_error("merge: parts must be 1..64");
+	if (parts > 64 || parts < 1 || topk < 1) {
+		h->set_error("merge: parts must be 1..64, topk >= 1");
 		return 0;
 	}
 	hipStream_t s = static_cast<hipStream_t>(stream);
-	hipLaunchKernelGGL(merge_topk_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_ids, d_l2, d_n, parts, nq, topk,
-	                   d_out_ids, d_out_l2, d_out_n);
+	hipLaunchKernelGGL(merge_topk_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_ids, d_l2, d_n, (size_t)nq * topk * 4,
+	                   (size_t)nq * topk * 8, (size_t)nq * 4, parts, nq, topk, d_out_ids, d_out_l2, d_out_n);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+size_t mvdb_topk_block_bytes(int nq, int topk)
+{
+	if (nq < 0 || topk < 1) return 0;
+	return ((size_t)nq * topk * 12 + (size_t)nq * 4 + 7) & ~(size_t)7;
+}
+
+int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, int nq, int topk, int32_t *d_out_ids,
+                               double *d_out_l2, int32_t *d_out_n, void *stream)
+{
+	if (!ensure_device(h)) return 0;
+	if (nq <= 0) return 1;
+	if (parts > 64 || parts < 1 || topk < 1) {
+		h->set_error("merge: parts must be 1..64, topk >= 1");
+		return 0;
+	}
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const size_t block = mvdb_topk_block_bytes(nq, topk);
+	const char *base = static_cast<const char *>(d_blocks);
+	const double *l2 = reinterpret_cast<const double *>(base);
+	const int32_t *ids = reinterpret_cast<const int32_t *>(base + (size_t)nq * topk * 8);
+	const int32_t *n = reinterpret_cast<const int32_t *>(base + (size_t)nq * topk * 12);
+	hipLaunchKernelGGL(merge_topk_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, ids, l2, n, block, block, block, parts, nq,
+	                   topk, d_out_ids, d_out_l2, d_out_n);
 	HIP_OK(h, hipGetLastError());
 	return 1;
 }

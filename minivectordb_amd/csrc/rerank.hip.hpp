@@ -325,25 +325,37 @@ __global__ __launch_bounds__(64) void prep_kernel(const float *q_in, int nq, int
 }
 
 // ---- merge of per-shard top-k lists: one thread per query ------------------
-__global__ void merge_topk_kernel(const int32_t *ids, const double *l2, const int32_t *n, int parts, int nq,
-                                  int topk, int32_t *out_ids, double *out_l2, int32_t *out_n)
+// Part p's arrays start p * stride bytes after the base pointers (dense [part][nq][topk] arrays, or the
+// packed per-rank blocks {l2 f64 | ids i32 | n i32} that one all-gather lays out back to back).
+__global__ void merge_topk_kernel(const int32_t *ids, const double *l2, const int32_t *n, size_t stride_ids, size_t stride_l2,
+                                  size_t stride_n, int parts, int nq, int topk, int32_t *out_ids, double *out_l2,
+                                  int32_t *out_n)
 {
 	const int qi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (qi >= nq) return;
+	auto ids_of = [&](int p) { return reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ids) + (size_t)p * stride_ids); };
+	auto l2_of = [&](int p) { return reinterpret_cast<const double *>(reinterpret_cast<const char *>(l2) + (size_t)p * stride_l2); };
+	auto n_of = [&](int p) { return reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(n) + (size_t)p * stride_n); };
 	int head[64];
 	for (int p = 0; p < parts; p++) head[p] = 0;
 	int emitted = 0;
-	for (; emitted < topk; emitted++) {
+	bool failed = false;  // a shard reported an aborted query (n = -1): the merged answer is not valid either
+	for (int p = 0; p < parts; p++) failed |= n_of(p)[qi] < 0;
+	for (; !failed && emitted < topk; emitted++) {
 		int bp = -1;
 		double bl = 0;
 		int bi = 0;
 		for (int p = 0; p < parts; p++) {
-			if (head[p] >= n[(size_t)p * nq + qi]) continue;
-			const size_t o = ((size_t)p * nq + qi) * topk + head[p];
-			if (bp < 0 || key_less(l2[o], ids[o], bl, bi)) {
+			int np = n_of(p)[qi];
+			if (np > topk) np = topk;
+			if (head[p] >= np) continue;
+			const size_t o = (size_t)qi * topk + head[p];
+			const double cl = l2_of(p)[o];
+			const int ci = ids_of(p)[o];
+			if (bp < 0 || key_less(cl, ci, bl, bi)) {
 				bp = p;
-				bl = l2[o];
-				bi = ids[o];
+				bl = cl;
+				bi = ci;
 			}
 		}
 		if (bp < 0) break;
@@ -351,7 +363,7 @@ __global__ void merge_topk_kernel(const int32_t *ids, const double *l2, const in
 		out_ids[(size_t)qi * topk + emitted] = bi;
 		out_l2[(size_t)qi * topk + emitted] = bl;
 	}
-	out_n[qi] = emitted;
+	out_n[qi] = failed ? -1 : emitted;
 }
 
 }  // namespace mvdb

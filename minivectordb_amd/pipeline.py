@@ -13,6 +13,7 @@ import ctypes as C
 import torch
 
 from .bridge import HipBridge
+from .distributed import TopkBlock
 
 
 class ResidentSearcher:
@@ -22,9 +23,9 @@ class ResidentSearcher:
         self.b, self.L, self.h = bridge, bridge._L, bridge.handle
         self.device = device
         self.topk = int(topk)
-        self.out_ids = torch.empty((nq_max, self.topk), dtype=torch.int32, device=device)
-        self.out_l2 = torch.empty((nq_max, self.topk), dtype=torch.float64, device=device)
-        self.out_n = torch.empty((nq_max,), dtype=torch.int32, device=device)
+        # outputs live in ONE packed block {l2 | ids | n}: the unit of the sharded path's single all-gather
+        self.out_block = TopkBlock(nq_max, self.topk, device=device)
+        self.out_ids, self.out_l2, self.out_n = self.out_block.ids, self.out_block.l2, self.out_block.n
         self.ctr = torch.zeros((nq_max, 4), dtype=torch.int32, device=device)
 
     def query_many(self, q_f32: torch.Tensor, ef_search: int, ann_k: int, allow: torch.Tensor | None = None):
@@ -62,16 +63,16 @@ class ResidentSearcher:
         self._b_streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         self._slots = []
         for _ in range(max(2, depth)):
+            blk = TopkBlock(nq, self.topk, device=dev)
             self._slots.append(dict(
+                block=blk,
                 qf=torch.empty((nq, dim), dtype=torch.float32, device=dev),
                 q8=torch.empty((nq, dim), dtype=torch.int8, device=dev),
                 cand=torch.empty((nq, max(ann_k, 1)), dtype=torch.int32, device=dev),
                 dist=torch.empty((nq, max(ann_k, 1)), dtype=torch.float32, device=dev),
                 cnt=torch.empty((nq,), dtype=torch.int32, device=dev),
                 ctr=torch.zeros((nq, 4), dtype=torch.int32, device=dev),
-                ids=torch.empty((nq, self.topk), dtype=torch.int32, device=dev),
-                l2=torch.empty((nq, self.topk), dtype=torch.float64, device=dev),
-                n=torch.empty((nq,), dtype=torch.int32, device=dev),
+                ids=blk.ids, l2=blk.l2, n=blk.n,
                 ready=torch.cuda.Event(), done=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False,
                 has_consumer=False))
 
@@ -181,6 +182,21 @@ class ResidentSearcher:
                                         C.c_void_p(out_n.data_ptr()), C.c_void_p(stream))
         self.b._check(ok)
         return out_ids, out_l2, out_n
+
+    def slot_block(self, slot: int) -> TopkBlock:
+        """The packed result block of a submitted batch (valid after wait(slot))."""
+        return self._slots[slot]["block"]
+
+    def merge_blocks(self, full: torch.Tensor, nq: int):
+        """Merge gathered per-shard blocks [parts, block_bytes] by (l2, id) on the device -> a TopkBlock."""
+        parts = int(full.shape[0])
+        out = TopkBlock(nq, self.topk, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ok = self.L.mvdb_merge_topk_packed_dev(self.h, C.c_void_p(full.data_ptr()), parts, int(nq), self.topk,
+                                               C.c_void_p(out.ids.data_ptr()), C.c_void_p(out.l2.data_ptr()),
+                                               C.c_void_p(out.n.data_ptr()), C.c_void_p(stream))
+        self.b._check(ok)
+        return out
 
     def stage_stats(self, stage: int, reset: bool = True):
         launches, total = C.c_longlong(0), C.c_double(0.0)

@@ -187,6 +187,17 @@ def test_merge_topk_kernel_matches_host_merge(gpu):
     for q in range(nq):
         assert np.array_equal(oi.cpu().numpy()[q, :en[q]], ei[q, :en[q]])
         assert np.array_equal(ol.cpu().numpy()[q, :en[q]], el[q, :en[q]])
+    # the packed form (one block per shard, as ONE all-gather delivers them), with an aborted query on one shard
+    from minivectordb_amd.distributed import TopkBlock
+    n[3, 17] = -1
+    full = torch.stack([TopkBlock(nq, topk).fill(ids[p], l2[p], n[p]).buf for p in range(parts)]).to(dev)
+    blk = s.merge_blocks(full, nq)
+    ei, el, en = merge_topk_host(ids, l2, n, topk)
+    assert en[17] == -1 and np.array_equal(blk.n.cpu().numpy(), en)
+    for q in range(nq):
+        k = max(en[q], 0)
+        assert np.array_equal(blk.ids.cpu().numpy()[q, :k], ei[q, :k])
+        assert np.array_equal(blk.l2.cpu().numpy()[q, :k], el[q, :k])
 
 
 def test_node_napi_bridge(gpu):
