@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- searchMany QPS @ recall@10 on MI355X (BASELINE.json metric).
 
-A "step" = one searchMany batch through the fused device pipeline
-(normalise+quantise -> HNSW traversal ef=annK -> float32 rerank -> top-10), queries
-and results resident in HBM.  Workload at N=1: BASELINE configs[1] -- 1M x 384-d
-synthetic normalised vectors, balanced preset (M=16, efc=300, ef=annK=1200),
-1k-query batches.
+A "step" = one searchMany batch through the fused device pipeline (normalise + quantise -> HNSW traversal with
+ef = annK -> float32 rerank -> top-10), queries and results resident in HBM.  Workload at N=1: BASELINE
+configs[1] -- 1M x 384-d synthetic normalised vectors, balanced preset (M=16, efc=300, ef=annK=1200), 1k-query
+batches; `--n 10000000` is the north-star size (10M x 384 balanced on one GPU).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU modes: "replicas" (default: the index fits one GPU, each rank
-answers its own query batch, results all-gathered; weak scaling in queries) and
-"sharded" (each rank holds an id-range shard, every rank sees every query, per-shard
-top-k all-gathered over RCCL and merged by (l2, id)).
+What one run reports (ONE JSON line, rank 0):
+  value                    K timed steps, inputs resident, `--in-flight` batches overlapping on as many streams,
+                           `--batches` DISTINCT query batches rotated (no batch is answered twice in a row)
+  median_ms_per_step       median interval between consecutive batch completions (HIP events)
+  pcie_inclusive           the same steps with the H2D of the queries and the D2H of the results inside (N=1)
+  sustained                the same steps repeated for >= `--sustain-s` seconds
+  roofline                 traversal kernel: algorithmic bytes per launch (from the kernel's own
+                           counters) / mean launch duration (HIP events on the launching stream, timed region only)
+  cpu_baseline             the C oracle (a restatement of the WASM path) on a bounded sample, 1 thread and all cores;
+                           the same leg asserts that the GPU results equal the oracle's on that sample
+  second_dataset           the same pipeline on a clustered set (neighbourhood structure, recall >= 0.9)
+N>1: headline = SHARDED (each rank an id-range shard of `--n` vectors with its own sub-index, every
+rank sees every query, ONE packed all-gather of the per-shard top-k per batch + (l2, id) merge); `replicas` = the
+ranks answering their own batches with no exchange, as a second field.
 
-Prints ONE JSON line (rank 0).  The graph is produced by the engine's own multi-threaded
-builder (reference insert algorithm, not its sequential order) because no reference
-dump of this size exists; parity on that dump is checked against the CPU oracle on a
-sample inside the cpu_baseline leg.
+`--workload scan`: BASELINE configs[2] -- exact int8 brute-force scan on the matrix cores (1M x 512, 4k queries),
+with the HNSW path's recall against that exact result.
+
+The graph comes from the engine's GPU bulk builder (reference insert algorithm applied block-parallel; no
+reference dump of this size can exist: the 32-bit WASM holds ~3.5 M nodes); parity on that dump is checked
+against the CPU oracle on a sample inside the cpu_baseline leg.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import threading
@@ -35,7 +47,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2x the ~2.5 PF dense bf16 rate (same guide, Matrix cores)
+CLUSTERS, CLUSTER_SIGMA, CLUSTER_QUERY_SIGMA = 4096, 0.35, 0.05
 
 
 def log(msg):
@@ -65,34 +79,535 @@ def run_with_heartbeat(fn, what):
     return box.get("r")
 
 
+def make_rows(n, dim, seed, clustered):
+    """Synthetic rows before normalisation: i.i.d. N(0,1) or a Gaussian mixture."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, dim), np.float32)
+    centers = rng.standard_normal((CLUSTERS, dim), dtype=np.float32) if clustered else None
+    chunk = 131072
+    for s in range(0, n, chunk):
+        c = min(chunk, n - s)
+        x = rng.standard_normal((c, dim), dtype=np.float32)
+        if clustered:
+            x = centers[rng.integers(0, CLUSTERS, c)] + CLUSTER_SIGMA * x
+        out[s:s + c] = x
+    return out
+
+
+def make_queries(nb, nq, dim, seed, base_norm, clustered):
+    rng = np.random.default_rng(seed)
+    if not clustered:  # distinct from the base, same distribution
+        return rng.standard_normal((nb, nq, dim), dtype=np.float32)
+    pick = rng.integers(0, base_norm.shape[0], nb * nq)  # a stored point plus a little noise
+    return (base_norm[pick] + CLUSTER_QUERY_SIGMA * rng.standard_normal((nb * nq, dim), dtype=np.float32)
+            / np.float32(math.sqrt(dim))).reshape(nb, nq, dim).astype(np.float32)
+
+
+def normalise_quantise(bridge, rows):
+    """normalizeF32InPlace + quantizeToI8 exactly as insertMany would (device prep kernel, bit-exact)."""
+    b8 = np.empty(rows.shape, np.int8)
+    for s in range(0, rows.shape[0], 131072):
+        rows[s:s + 131072], b8[s:s + 131072] = bridge.prepareQueries(rows[s:s + 131072])
+    return rows, b8
+
+
+def exact_topk(torch, dev, base, qn, tk, id_offset=0):
+    """Exact float32 top-k by brute force on the device (unit vectors: smallest L2 == largest dot)."""
+    nq = qn.shape[0]
+    q = torch.from_numpy(qn).to(dev)
+    best_d = torch.full((nq, tk), float("inf"), device=dev)
+    best_i = torch.full((nq, tk), -1, dtype=torch.int64, device=dev)
+    for s in range(0, base.shape[0], 262144):
+        bt = torch.from_numpy(base[s:s + 262144]).to(dev)
+        d = 2.0 - 2.0 * (q @ bt.T)
+        dd, ii = torch.topk(d, min(tk, bt.shape[0]), dim=1, largest=False)
+        cat_d, cat_i = torch.cat([best_d, dd], 1), torch.cat([best_i, ii + s + id_offset], 1)
+        sel = torch.topk(cat_d, tk, dim=1, largest=False).indices
+        best_d, best_i = torch.gather(cat_d, 1, sel), torch.gather(cat_i, 1, sel)
+        del bt, d
+    return best_d, best_i
+
+
+def recall_of(got, gt, tk):
+    return float(np.mean([len(set(got[i, :tk].tolist()) & set(gt[i].tolist())) / tk for i in range(got.shape[0])]))
+
+
+class Pipeline:
+    """One index + resident query batches + the step function of the timed region."""
+
+    def __init__(self, args, torch, dev, rank, world, sharded, clustered, n, label):
+        from minivectordb_amd import HipBridge, derive_search_params, resolve_preset
+        from minivectordb_amd.pipeline import ResidentSearcher
+        self.args, self.torch, self.dev, self.rank, self.world, self.sharded = args, torch, dev, rank, world, sharded
+        self.preset = resolve_preset(args.preset)
+        self.tk, self.ef_search, self.ann_k = derive_search_params(args.topk, self.preset)
+        self.n, self.dim, self.nq, self.nb = n, args.dim, args.nq, max(1, args.batches)
+        self.clustered, self.label = clustered, label
+        self.id_offset = rank * n if sharded else 0
+        p = self.preset
+        t0 = time.time()
+        rows = make_rows(n, self.dim, 12345 + (rank if world > 1 else 0) + (777 if clustered else 0), clustered)
+        self.bridge = HipBridge(device=dev.index)
+        self.bridge.init(dict(dim=self.dim, m=p["m"], ef=p["ef_construction"], efSearch=p["baseEfSearch"], capacity=n,
+                              seed=42, resultsCap=p["resultsCap"]))
+        self.base, self.base8 = normalise_quantise(self.bridge, rows)
+        log(f"rank {rank} [{label}]: {n}x{self.dim} rows generated, normalised + quantised in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        if args.builder == "gpu":
+            self.build_stats = run_with_heartbeat(lambda: self.bridge.buildGpu(self.base8), f"rank {rank}: GPU build")
+            self.graph = ("engine GPU bulk builder (reference insert algorithm, block-parallel; not the "
+                          "reference's sequential edge order)")
+        else:
+            run_with_heartbeat(lambda: self.bridge.buildParallel(self.base8, args.build_threads),
+                               f"rank {rank}: host build ({args.build_threads} threads)")
+            self.build_stats = None
+            self.graph = "engine multi-threaded host builder (reference insert algorithm, unordered)"
+        self.build_s = time.time() - t0
+        log(f"rank {rank} [{label}]: built {self.bridge.elementCount()} nodes in {self.build_s:.1f}s")
+        self.bridge.attachF32(self.base, resident=not args.host_f32)
+        self.bridge.setTuning(traverse_waves=args.traverse_waves, rerank_waves=2 if args.in_flight >= 2 else 0)
+        # queries: replicated in sharded mode, per-rank otherwise
+        q_seed = 54321 + (rank if (world > 1 and not sharded) else 0)
+        self.q_host = make_queries(self.nb, self.nq, self.dim, q_seed, self.base, clustered)
+        self.q_dev = torch.from_numpy(self.q_host).to(dev)
+        self.searcher = ResidentSearcher(self.bridge, self.nq, self.tk, dev)
+        self.step_i = 0
+        self.events = []
+
+    # -- reference pass: per-batch results (single stream) and work counters
+    def reference_pass(self):
+        torch = self.torch
+        self.ref, self.ctr = [], []
+        for i in range(self.nb):
+            ids, l2, n = self.searcher.query_many(self.q_dev[i], self.ef_search, self.ann_k)
+            torch.cuda.synchronize(self.dev)
+            self.ref.append((ids.clone(), l2.clone(), n.clone()))
+            self.ctr.append(self.searcher.ctr[:self.nq].cpu().numpy().astype(np.int64))
+        self.searcher.check()
+        p = self.preset
+        m, m0 = p["m"], 2 * p["m"]
+        # SURVEY.md 8(d): B_ann = n_dist*DIM + n_L0lists*(4+4*M_MAX0) + n_upperlists*(4+4*M) + DIM per query
+        self.b_ann = [int((c[:, 0] * self.dim + c[:, 1] * (4 + 4 * m0) + c[:, 2] * (4 + 4 * m) + self.dim).sum())
+                      for c in self.ctr]
+        self.b_rerank = [int((c[:, 3] * self.dim * 4 + self.dim * 4 + self.tk * 8).sum()) for c in self.ctr]
+
+    def step(self, exchange=True, record=False):
+        a, s = self.args, self.searcher
+        i = self.step_i % self.nb
+        self.step_i += 1
+        q = self.q_dev[i]
+        if a.in_flight >= 2:
+            slot, ids, l2, n = s.submit_interleaved(q, self.ef_search, self.ann_k, sync_with_current=False, depth=a.in_flight)
+            if record:
+                ev = self.torch.cuda.Event(enable_timing=True)
+                ev.record(s._b_streams[slot])
+                self.events.append(ev)
+            if not (self.sharded and exchange):
+                return slot, i
+            s.wait(slot)
+            block = s.slot_block(slot)
+        else:
+            ids, l2, n = s.query_many(q, self.ef_search, self.ann_k)
+            if record:
+                ev = self.torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.events.append(ev)
+            if not (self.sharded and exchange):
+                return -1, i
+            slot, block = -1, s.out_block
+        from minivectordb_amd.distributed import sharded_exchange
+        self.merged = sharded_exchange(block, self.id_offset, lambda full: s.merge_blocks(full, self.nq))
+        if slot >= 0:
+            s.release(slot)  # the all-gather above is the last reader of this slot's block
+        return slot, i
+
+    def timed(self, steps, exchange=True, record=False):
+        """barrier + sync | steps | drain + sync + barrier -> seconds (max over ranks)."""
+        import torch.distributed as dist
+        torch, dev = self.torch, self.dev
+        self.events = []
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        last = []
+        for _ in range(steps):
+            last.append(self.step(exchange, record))
+        if self.args.in_flight >= 2:
+            self.searcher.drain()
+        torch.cuda.synchronize(dev)
+        if self.world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        self.last_steps = last
+        return el
+
+    def check_last_steps(self):
+        """Overlapped batches must return the bits of the one-at-a-time reference pass."""
+        torch, s, D = self.torch, self.searcher, self.args.in_flight
+        if self.sharded:
+            return
+        seen = set()
+        for slot, i in reversed(self.last_steps):
+            if slot in seen:
+                break
+            seen.add(slot)
+            blk = s.slot_block(slot) if slot >= 0 else s.out_block
+            r_ids, r_l2, r_n = self.ref[i]
+            assert torch.equal(blk.ids[:self.nq], r_ids) and torch.equal(blk.l2[:self.nq], r_l2) and \
+                torch.equal(blk.n[:self.nq], r_n), "overlapped and one-at-a-time results differ"
+            if D < 2:
+                break
+
+    def median_interval_ms(self):
+        if len(self.events) < 3:
+            return None
+        self.torch.cuda.synchronize(self.dev)
+        # batches on different streams may complete out of submission order: sort the completion times first
+        t = sorted(self.events[0].elapsed_time(e) for e in self.events)
+        gaps = sorted(t[j + 1] - t[j] for j in range(len(t) - 1))
+        return float(gaps[len(gaps) // 2])
+
+    def pcie_inclusive(self, steps):
+        """Steps that start from pinned host queries and end with the results in pinned host memory."""
+        torch, dev, s, a = self.torch, self.dev, self.searcher, self.args
+        D = max(a.in_flight, 2)
+        qh = torch.from_numpy(self.q_host).pin_memory()
+        stage = [torch.empty((self.nq, self.dim), dtype=torch.float32, device=dev) for _ in range(D)]
+        from minivectordb_amd.distributed import block_bytes
+        outs = [torch.empty(block_bytes(self.nq, self.tk), dtype=torch.uint8).pin_memory() for _ in range(D)]
+        s._pipe_init(self.nq, self.dim, int(self.ann_k), D)
+
+        def one(j):
+            slot = s._pipe_i % D
+            S = s._b_streams[slot]
+            with torch.cuda.stream(S):
+                stage[slot].copy_(qh[j % self.nb], non_blocking=True)
+            sl, *_ = s.submit_interleaved(stage[slot], self.ef_search, self.ann_k, sync_with_current=False, depth=D)
+            assert sl == slot
+            with torch.cuda.stream(S):
+                outs[slot].copy_(s.slot_block(slot).buf, non_blocking=True)
+
+        for j in range(3):
+            one(j)
+        s.drain()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for j in range(steps):
+            one(j)
+        s.drain()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    def recall(self):
+        """recall@10 of batch 0 against the exact float32 top-10 (over ALL shards when sharded)."""
+        import torch.distributed as dist
+        from minivectordb_amd.distributed import TopkBlock, gather_blocks, merge_blocks_host
+        torch, dev = self.torch, self.dev
+        qn, _ = self.bridge.prepareQueries(self.q_host[0])
+        gt_d, gt_i = exact_topk(torch, dev, self.base, qn, self.tk, self.id_offset)
+        if self.sharded:
+            blk = TopkBlock(self.nq, self.tk, device=dev).fill(gt_i.to(torch.int32), gt_d.to(torch.float64),
+                                                               torch.full((self.nq,), self.tk, dtype=torch.int32))
+            gt_i = torch.from_numpy(merge_blocks_host(gather_blocks(blk.buf), self.nq, self.tk)[0])
+            self.step_i = 0
+            self.step(exchange=True)
+            torch.cuda.synchronize(dev)
+            got = self.merged.ids.cpu().numpy()
+        else:
+            got = self.ref[0][0].cpu().numpy()
+        return recall_of(got, gt_i.cpu().numpy(), self.tk)
+
+    def close(self):
+        self.bridge.close()
+
+
+def cpu_baseline_leg(pl, args):
+    """The C oracle (restatement of the WASM path) on the first queries of batch 0, same dump."""
+    from oracle import oracle as O
+    p = pl.preset
+    ns = min(args.cpu_sample, pl.nq)
+    ix = O.OracleIndex(pl.dim, p["m"], p["ef_construction"], 8, seed=1)
+    t0 = time.time()
+    assert ix.load_bytes(pl.bridge.saveBytes()), "oracle rejected the engine's dump"
+    log(f"oracle loaded the dump in {time.time() - t0:.1f}s; timing {ns} queries on 1 host thread")
+    q = pl.q_host[0][:ns]
+    t0 = time.perf_counter()
+    o_ids, o_l2, o_n, ann_ids, ann_cnt, octr = O.search_many_db(ix, q, pl.base, args.topk, args.preset, threads=1)
+    cpu_s = time.perf_counter() - t0
+    g_ids, g_l2, g_n = (t[:ns].cpu().numpy() for t in pl.ref[0])
+    same = bool(np.array_equal(o_ids, g_ids) and np.array_equal(o_n, g_n) and
+                np.array_equal(o_l2.view(np.uint64), g_l2.view(np.uint64)) and
+                np.array_equal(octr["n_dist"], pl.ctr[0][:ns, 0]))
+    nthr = max(1, min(args.build_threads, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    O.search_many_db(ix, q, pl.base, args.topk, args.preset, threads=nthr)
+    cpu_mt_s = time.perf_counter() - t0
+    ix.close()
+    return dict(value=round(ns / cpu_s, 2), unit="queries/s", cores=1, kind="port",
+                sample=f"first {ns} of the {pl.nq} queries of batch 0, full searchMany pipeline on the same "
+                       f"{pl.n}-node dump (C restatement of the WASM path; 1 thread = the reference's sequential loop)",
+                all_cores=dict(value=round(ns / cpu_mt_s, 2), cores=nthr),
+                gpu_matches_oracle_on_sample=same)
+
+
+def traffic_record(pl, kernel):
+    """HBM bytes per traversal launch from the committed PMC passes of THIS workload (profiles/), if any."""
+    name = f"pmc_traffic_{pl.n // 1_000_000}m_{pl.args.preset}.json"
+    for rnd in ("r2", "r1"):
+        f = os.path.join(ROOT, "profiles", rnd, name)
+        if pl.n % 1_000_000 == 0 and pl.dim == 384 and pl.nq == 1000 and not pl.clustered and os.path.exists(f):
+            with open(f) as fh:
+                rec = json.load(fh).get("traverse", {})
+            if rec.get("kernel") == kernel and "corrected_bytes_per_launch" in rec:
+                return int(rec["corrected_bytes_per_launch"]), f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of this workload)"
+    return None, None
+
+
+def run_hnsw(args, torch, dist, dev, rank, world):
+    sharded = world > 1 and args.mode != "replicas"
+    pl = Pipeline(args, torch, dev, rank, world, sharded, False, args.n, "iid")
+    bridge, s = pl.bridge, pl.searcher
+    log(f"rank {rank}: reference pass over {pl.nb} distinct batches (first call uploads the index)")
+    pl.reference_pass()
+    for _ in range(args.warmup):
+        pl.step()
+    if args.in_flight >= 2:
+        s.drain()
+    torch.cuda.synchronize(dev)
+    bridge._L.mvdb_enable_timing(bridge.handle, 1)
+    for st in (0, 1, 2):
+        s.stage_stats(st)
+    pl.step_i = 0
+    elapsed = pl.timed(args.steps, record=True)
+    bridge._L.mvdb_enable_timing(bridge.handle, 0)
+    s.check()
+    pl.check_last_steps()
+    median_ms = pl.median_interval_ms()
+    ms_per_step = elapsed / args.steps * 1e3
+    per_step_queries = pl.nq * (world if (world > 1 and not sharded) else 1)
+    qps = per_step_queries / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (traversal): live HIP-event timing of the timed launches only
+    n_launch, trav_ms_total = s.stage_stats(1)
+    _, rerank_ms_total = s.stage_stats(2)
+    _, prep_ms_total = s.stage_stats(0)
+    bytes_timed = sum(pl.b_ann[j % pl.nb] for j in range(args.steps))
+    rerank_bytes_timed = sum(pl.b_rerank[j % pl.nb] for j in range(args.steps))
+    trav_ms = trav_ms_total / max(n_launch, 1)
+    bytes_per_launch = bytes_timed / max(args.steps, 1)
+    achieved = bytes_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+    m0 = 2 * pl.preset["m"]
+    kernel = "traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else "traverse_duo_kernel"
+    traffic, traffic_source = traffic_record(pl, kernel)
+    roofline = dict(bound="hbm", kernel=kernel, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
+                    algorithmic_bytes_per_launch=int(bytes_per_launch), avg_launch_ms=round(trav_ms, 4),
+                    launches_timed=int(n_launch),
+                    rerank_bytes_per_launch=int(rerank_bytes_timed / max(args.steps, 1)),
+                    rerank_avg_launch_ms=round(rerank_ms_total / max(n_launch, 1), 4),
+                    prep_avg_launch_ms=round(prep_ms_total / max(n_launch, 1), 4),
+                    # launches overlap when several batches are in flight: `achieved` (per launch, by the
+                    # definition) then understates what the chip delivers; bytes of all timed launches / wall:
+                    effective_gbs=round(bytes_timed / elapsed / 1e9, 2),
+                    effective_frac=round(bytes_timed / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                    pipeline_gbs=round((bytes_timed + rerank_bytes_timed) / elapsed / 1e9, 2))
+
+    extras = {}
+    if world > 1 and sharded:  # the same ranks with no exchange: what "replicas" scaling would show
+        el = pl.timed(args.steps, exchange=False)
+        extras["replicas"] = dict(value=round(world * pl.nq / (el / args.steps), 2), unit="queries/s",
+                                  mode="every rank answers its own copy of the batch on its own index, no exchange "
+                                       "(embarrassingly parallel; says nothing about the sharded path)")
+    if world == 1 and not args.no_pcie:
+        el = pl.pcie_inclusive(args.steps)
+        extras["pcie_inclusive"] = dict(value=round(pl.nq / (el / args.steps), 2), unit="queries/s",
+                                        ms_per_step=round(el / args.steps * 1e3, 4),
+                                        what="each step copies its queries from pinned host memory and its results back")
+        s.check()
+    if args.sustain_s > 0:
+        k = max(args.steps, int(math.ceil(args.sustain_s / max(elapsed / args.steps, 1e-6))))
+        el = pl.timed(k)
+        extras["sustained"] = dict(value=round(per_step_queries / (el / k), 2), unit="queries/s", steps=k,
+                                   seconds=round(el, 3))
+        s.check()
+
+    recall = None if args.no_recall else pl.recall()
+    if world > 1 and rank != 0:
+        recall = None
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cpu_baseline = cpu_baseline_leg(pl, args)
+
+    ctr_all = np.concatenate(pl.ctr, 0)
+    out = None
+    if rank == 0:
+        p = pl.preset
+        out = dict(metric="searchMany QPS @ recall@10 (topK=10, 384-d int8+f32 rerank)",
+                   value=round(qps, 2), unit="queries/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="i8", dtype_detail="int8 rows, exact i32 distances (traversal); f32 rows, f64 accumulate (rerank)",
+                   data="synthetic",
+                   config=dict(workload=f"{pl.n}x{pl.dim} int8 HNSW (preset {args.preset}: M={p['m']}, efc="
+                                        f"{p['ef_construction']}, ef=annK={pl.ann_k}) + f32 rerank, batch {pl.nq} "
+                                        f"queries, topK={pl.tk}" + (f", {world} id-range shards of {pl.n}" if sharded else ""),
+                               n=pl.n, dim=pl.dim, nq=pl.nq, topk=pl.tk, ann_k=pl.ann_k, preset=args.preset,
+                               mode=("single" if world == 1 else ("sharded" if sharded else "replicas")),
+                               total_vectors=pl.n * (world if sharded else 1),
+                               batches=(f"{args.in_flight} in flight: batch i on stream i % {args.in_flight}"
+                                        if args.in_flight >= 2 else "one at a time"),
+                               distinct_query_batches=pl.nb, f32_store=("pinned host" if args.host_f32 else "HBM"),
+                               graph=pl.graph, build_seconds=round(pl.build_s, 2), build=pl.build_stats,
+                               exchange=("one packed all-gather of per-shard top-k blocks per batch + (l2,id) merge kernel"
+                                         if sharded else None)),
+                   median_ms_per_step=None if median_ms is None else round(median_ms, 4),
+                   recall_at_10=None if recall is None else round(recall, 4),
+                   roofline=roofline, cpu_baseline=cpu_baseline,
+                   counters=dict(mean_n_dist=float(ctr_all[:, 0].mean()), mean_n_l0lists=float(ctr_all[:, 1].mean()),
+                                 mean_n_upperlists=float(ctr_all[:, 2].mean())))
+        out.update(extras)
+    pl.close()
+    del pl
+
+    # ---- second synthetic set with neighbourhood structure (the i.i.d. line above stays the headline)
+    if world == 1 and args.second_dataset != "none" and (args.second_dataset == "clustered" or args.n <= 2_000_000):
+        p2 = Pipeline(args, torch, dev, rank, world, False, True, args.n, "clustered")
+        p2.reference_pass()
+        for _ in range(args.warmup):
+            p2.step()
+        p2.searcher.drain() if args.in_flight >= 2 else None
+        p2.step_i = 0
+        el = p2.timed(args.steps)
+        p2.searcher.check()
+        p2.check_last_steps()
+        c2 = np.concatenate(p2.ctr, 0)
+        out["second_dataset"] = dict(
+            data=f"{CLUSTERS} Gaussian clusters (centres N(0,1), sigma {CLUSTER_SIGMA}), queries = stored points + noise",
+            value=round(p2.nq / (el / args.steps), 2), unit="queries/s", ms_per_step=round(el / args.steps * 1e3, 4),
+            recall_at_10=None if args.no_recall else round(p2.recall(), 4), build_seconds=round(p2.build_s, 2),
+            mean_n_dist=float(c2[:, 0].mean()), mean_n_l0lists=float(c2[:, 1].mean()),
+            effective_gbs=round(sum(p2.b_ann[j % p2.nb] for j in range(args.steps)) / el / 1e9, 2))
+        p2.close()
+    return out
+
+
+def run_scan(args, torch, dist, dev, rank, world):
+    """BASELINE configs[2]: exact int8 brute-force scan on the matrix cores + the HNSW path's recall against it."""
+    from minivectordb_amd import HipBridge, resolve_preset
+    n, dim, nq, k = args.n, args.dim, args.nq, args.topk
+    p = resolve_preset(args.preset)
+    b = HipBridge(device=dev.index)
+    b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], efSearch=p["baseEfSearch"], capacity=n, seed=42,
+                resultsCap=4096))
+    base, b8 = normalise_quantise(b, make_rows(n, dim, 12345 + rank, False))
+    st = run_with_heartbeat(lambda: b.buildGpu(b8), "GPU build")
+    q8 = normalise_quantise(b, np.random.default_rng(54321 + rank).standard_normal((nq, dim), dtype=np.float32))[1]
+    qd = torch.from_numpy(q8).to(dev)
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    val = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    L, h, vp = b._L, b.handle, C.c_void_p
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        b._check(L.mvdb_scan_many_dev(h, vp(qd.data_ptr()), nq, k, 0, vp(ids.data_ptr()), vp(val.data_ptr()),
+                                      vp(cnt.data_ptr()), vp(stream)))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    L.mvdb_enable_timing(h, 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    L.mvdb_enable_timing(h, 0)
+    nl, tot = C.c_longlong(0), C.c_double(0.0)
+    L.mvdb_stage_stats(h, 3, C.byref(nl), C.byref(tot), 1)
+    scan_ms = tot.value / max(nl.value, 1)
+    ops = 2.0 * nq * n * dim
+    # HNSW (balanced traversal, int8 distances) recall@k against this exact int8 result
+    b.setEfSearch(p["baseEfSearch"])
+    hi, hd, hc = b.searchManyArrays(q8[:1000], k * p["rerankMultiplier"])
+    exact = ids[:1000].cpu().numpy()
+    hn_recall = recall_of(hi, exact, k)
+    cpu = None
+    if rank == 0 and args.cpu_sample > 0:
+        from oracle import oracle as O
+        ns = min(16, nq)
+        ix = O.OracleIndex(dim, p["m"], p["ef_construction"], 8, seed=1)
+        assert ix.load_bytes(b.saveBytes())
+        nthr = max(1, min(args.build_threads, os.cpu_count() or 1))
+        t1 = time.perf_counter()
+        oi, ov, oc = ix.scan_many(q8[:ns], k, "l2", threads=nthr)
+        cs = time.perf_counter() - t1
+        same = bool(np.array_equal(oi, ids[:ns].cpu().numpy()) and np.array_equal(ov, val[:ns].cpu().numpy()))
+        cpu = dict(value=round(ns / cs, 2), unit="queries/s", cores=nthr, kind="port",
+                   sample=f"first {ns} queries, exhaustive int8 scan of the same {n} rows (C oracle)",
+                   gpu_matches_oracle_on_sample=same)
+        ix.close()
+    out = None
+    if rank == 0:
+        out = dict(metric="exact int8 scan QPS (top-10, int8 MFMA)", value=round(world * nq / (el / args.steps), 2),
+                   unit="queries/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(el / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="i8", data="synthetic",
+                   config=dict(workload=f"{n}x{dim} exact int8 brute-force scan, batch {nq} queries, top-{k}", n=n, dim=dim,
+                               nq=nq, topk=k, mode="single" if world == 1 else "replicas", build=st),
+                   roofline=dict(bound="mfma", kernel="scan_kernel", achieved=round(ops / (scan_ms * 1e-3) / 1e12, 2),
+                                 peak=I8_MFMA_PEAK_TOPS, unit="TOP/s (int8 multiply-add = 2 ops)",
+                                 frac=round(ops / (scan_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, 5), traffic=None,
+                                 ops_per_launch=ops, avg_launch_ms=round(scan_ms, 4)),
+                   hnsw_recall_vs_exact_int8=dict(value=round(hn_recall, 4), queries=1000,
+                                                  what=f"traversal candidates (ef={k * p['rerankMultiplier']}) top-{k} by "
+                                                       f"int8 distance vs the exact scan's top-{k}"),
+                   cpu_baseline=cpu)
+    b.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="vectors per index (per shard when sharded)")
-    ap.add_argument("--nq", type=int, default=1000, help="queries per batch")
-    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--workload", default="hnsw", choices=["hnsw", "scan"])
+    ap.add_argument("--n", type=int, default=None, help="vectors per index (per shard when sharded); default 1M")
+    ap.add_argument("--nq", type=int, default=None, help="queries per batch (default 1000; scan: 4096)")
+    ap.add_argument("--dim", type=int, default=None, help="default 384 (scan: 512)")
     ap.add_argument("--preset", default="balanced")
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"],
+                    help="N>1: sharded (default, the north_star path) or replicas")
+    ap.add_argument("--builder", default="gpu", choices=["gpu", "host"])
     ap.add_argument("--build-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--batches", type=int, default=8, help="distinct query batches rotated through the steps")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of the sustained leg (0 = skip)")
+    ap.add_argument("--second-dataset", default="auto", choices=["auto", "none", "clustered"])
+    ap.add_argument("--host-f32", action="store_true", help="float32 store in pinned host memory (preloadVectors=false)")
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="batches in flight: batch i runs on stream i %% IN_FLIGHT (the next batches' workgroups "
-                         "fill the places of queries that finished early); 1 = one batch at a time")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="batch i's rerank on a second stream under batch i+1's traversal (measured slower on "
-                         "MI355X: 4.52 vs 4.34 ms per batch, DESIGN.md 4.1; default: one batch at a time)")
+                    help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
+    ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1, 2, 3], help="0 = the engine's default")
     args = ap.parse_args()
+    scan = args.workload == "scan"
+    args.n = args.n or 1_000_000
+    args.nq = args.nq or (4096 if scan else 1000)
+    args.dim = args.dim or (512 if scan else 384)
 
     import torch
     import torch.distributed as dist
-
-    from minivectordb_amd import HipBridge, resolve_preset, derive_search_params
-    from minivectordb_amd.distributed import gather_topk
-    from minivectordb_amd.pipeline import ResidentSearcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,235 +619,11 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    preset = resolve_preset(args.preset)
-    N, nq, dim, topk = args.n, args.nq, args.dim, args.topk
-    tk, ef_search, ann_k = derive_search_params(topk, preset)
-
-    # ---------------- data: synthetic normalised vectors --------------
-    sharded = world > 1 and args.mode == "sharded"
-    base_seed = 12345 + (rank if sharded else 0)
-    t0 = time.time()
-    rng = np.random.default_rng(base_seed)
-    base = np.empty((N, dim), np.float32)
-    chunk = 131072
-    for s in range(0, N, chunk):
-        base[s:s + chunk] = rng.standard_normal((min(chunk, N - s), dim), dtype=np.float32)
-    log(f"rank {rank}: generated {N}x{dim} gaussian base in {time.time() - t0:.1f}s")
-
-    bridge = HipBridge(device=local_rank)
-    bridge.init(dict(dim=dim, m=preset["m"], ef=preset["ef_construction"], efSearch=preset["baseEfSearch"],
-                     capacity=N, seed=42, resultsCap=preset["resultsCap"]))
-    # normalise + quantise exactly as insertMany would (device prep kernel, bit-exact to the reference)
-    t0 = time.time()
-    base8 = np.empty((N, dim), np.int8)
-    for s in range(0, N, chunk):
-        qn, q8 = bridge.prepareQueries(base[s:s + chunk])
-        base[s:s + chunk] = qn
-        base8[s:s + chunk] = q8
-    log(f"rank {rank}: normalised+quantised on device in {time.time() - t0:.1f}s")
-
-    # ---------------- graph: built once (rank 0 in replicas mode), shared as a V3 dump --------
-    t0 = time.time()
-    if sharded or world == 1 or rank == 0:
-        run_with_heartbeat(lambda: bridge.buildParallel(base8, args.build_threads),
-                           f"rank {rank}: building HNSW graph ({args.build_threads} threads)")
-        log(f"rank {rank}: built {bridge.elementCount()} nodes in {time.time() - t0:.1f}s")
-    if world > 1 and not sharded:
-        if rank == 0:
-            dump = np.frombuffer(bridge.saveBytes(), np.uint8)
-            size = torch.tensor([dump.size], dtype=torch.int64, device=dev)
-        else:
-            size = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.broadcast(size, 0)
-        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            buf.copy_(torch.from_numpy(dump.copy()))
-        dist.broadcast(buf, 0)
-        if rank != 0:
-            bridge.loadBytes(buf.cpu().numpy().tobytes())
-        del buf
-    bridge.attachF32(base, resident=True)
-
-    # ---------------- queries ------------------------------------------------------------------
-    q_seed = 54321 + (rank if (world > 1 and not sharded) else 0)
-    q_host = np.random.default_rng(q_seed).standard_normal((nq, dim), dtype=np.float32)
-    q_dev = torch.from_numpy(q_host).to(dev)
-    searcher = ResidentSearcher(bridge, nq, tk, dev)
-    id_offset = rank * N if sharded else 0
-
-    pipelined = args.pipeline
-    interleaved = args.in_flight >= 2 and not pipelined
-    if pipelined or interleaved:
-        # 2-wave rerank workgroups (34 KB of LDS) find room beside running traversals: +2 % with 3 in flight
-        os.environ.setdefault("MVDB_RERANK_WAVES", "2")
-
-    def step():
-        if pipelined or interleaved:
-            if pipelined:
-                slot, ids, l2, n = searcher.submit(q_dev, ef_search, ann_k)
-            else:  # q_dev is resident and never rewritten: no need to order the batch behind this stream
-                slot, ids, l2, n = searcher.submit_interleaved(q_dev, ef_search, ann_k, sync_with_current=False,
-                                                                   depth=args.in_flight)
-            if world == 1:
-                return ids, l2, n
-            searcher.wait(slot)
-        else:
-            ids, l2, n = searcher.query_many(q_dev, ef_search, ann_k)
-            if world == 1:
-                return ids, l2, n
-        if sharded:
-            gid = ids + id_offset if id_offset else ids
-            all_ids, all_l2, all_n = gather_topk(gid, l2, n)          # the one exchange step (RCCL all-gather)
-            out = searcher.merge_topk(all_ids, all_l2, all_n, world, nq)
-        else:  # replicas: every rank ends up with every rank's answers
-            out = gather_topk(ids, l2, n)
-        if pipelined or interleaved:
-            searcher.release(slot)  # the collectives above are the last readers of this slot's outputs
-        return out
-
-    # ---------------- warmup + timed region -----------------------------------------------------
-    log(f"rank {rank}: warmup {args.warmup} steps (first step uploads the index)")
-    for _ in range(args.warmup):
-        step()
-    if pipelined or interleaved:
-        searcher.drain()
-    torch.cuda.synchronize(dev)
-    bridge._L.mvdb_enable_timing(bridge.handle, 1)
-    searcher.stage_stats(0), searcher.stage_stats(1), searcher.stage_stats(2)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    if pipelined or interleaved:
-        searcher.drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    bridge._L.mvdb_enable_timing(bridge.handle, 0)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    ms_per_step = elapsed / args.steps * 1e3
-    queries_per_step = nq * (world if (world > 1 and not sharded) else 1)
-    qps = queries_per_step / (elapsed / args.steps)
-
-    # ---------------- roofline of the dominant kernel (traversal), live HIP-event timing ---------
-    n_launch, trav_ms_total = searcher.stage_stats(1)
-    _, rerank_ms_total = searcher.stage_stats(2)
-    _, prep_ms_total = searcher.stage_stats(0)
-    ctr = searcher.ctr[:nq].cpu().numpy().astype(np.int64)
-    m, m0 = preset["m"], 2 * preset["m"]
-    # B_ann = n_dist*DIM + n_L0lists*(4+4*M_MAX0) + n_upperlists*(4+4*M) + DIM per query
-    b_ann = ctr[:, 0] * dim + ctr[:, 1] * (4 + 4 * m0) + ctr[:, 2] * (4 + 4 * m) + dim
-    b_rerank = ctr[:, 3] * dim * 4 + dim * 4 + tk * 8
-    trav_ms = trav_ms_total / max(n_launch, 1)
-    achieved = float(b_ann.sum()) / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
-    # HBM traffic per launch: FETCH_SIZE from a separate rocprofv3 --pmc pass of this workload, corrected
-    # by the gfx950 calibration recorded next to it (profiles/r1/pmc_traffic_1m_balanced.json)
-    traffic = None
-    # two waves per query whenever a neighbour list fits one 64-lane chunk (engine.hip: traverse_use_duo)
-    kernel = "traverse_kernel" if (m0 > 64 or os.environ.get("MVDB_TRAVERSE_WAVES") == "1") else "traverse_duo_kernel"
-    pmc_file = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_1m_balanced.json")
-    if N == 1_000_000 and dim == 384 and nq == 1000 and args.preset == "balanced" and os.path.exists(pmc_file):
-        with open(pmc_file) as f:
-            pmc = json.load(f)["traverse"]
-        if pmc.get("kernel", "traverse_kernel") == kernel:
-            traffic = int(pmc["corrected_bytes_per_launch"])
-    roofline = dict(bound="hbm", kernel=kernel, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    algorithmic_bytes_per_launch=int(b_ann.sum()), avg_launch_ms=round(trav_ms, 4),
-                    rerank_bytes_per_launch=int(b_rerank.sum()),
-                    rerank_avg_launch_ms=round(rerank_ms_total / max(n_launch, 1), 4),
-                    prep_avg_launch_ms=round(prep_ms_total / max(n_launch, 1), 4),
-                    # launches overlap when several batches are in flight: `achieved` (per launch, by the
-                    # definition) then understates what the chip delivers; bytes of all timed launches / wall:
-                    effective_gbs=round(float(b_ann.sum()) * args.steps / elapsed / 1e9, 2),
-                    effective_frac=round(float(b_ann.sum()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                    pipeline_gbs=round(float(b_ann.sum() + b_rerank.sum()) / (ms_per_step * 1e-3) / 1e9, 2))
-
-    # ---------------- recall@10 vs exact float32 brute force (rank 0, own queries) --------------
-    recall = None
-    ids_dev, l2_dev, n_dev = searcher.query_many(q_dev, ef_search, ann_k)
-    torch.cuda.synchronize(dev)
-    got = ids_dev.cpu().numpy()
-    if (pipelined or interleaved) and world == 1:  # the overlapped batches answered the same queries: same bits expected
-        p_ids, p_l2, p_n = last
-        assert torch.equal(p_ids, ids_dev) and torch.equal(p_l2, l2_dev) and torch.equal(p_n, n_dev), \
-            "pipelined and single-stream results differ"
-    if not args.no_recall and rank == 0:
-        qn_host, _ = bridge.prepareQueries(q_host)
-        qn = torch.from_numpy(qn_host).to(dev)
-        best_d = torch.full((nq, tk), float("inf"), device=dev)
-        best_i = torch.full((nq, tk), -1, dtype=torch.int64, device=dev)
-        for s in range(0, N, 262144):  # unit vectors: smallest L2 == largest dot
-            bt = torch.from_numpy(base[s:s + 262144]).to(dev)
-            d = 2.0 - 2.0 * (qn @ bt.T)
-            dd, ii = torch.topk(d, tk, dim=1, largest=False)
-            cat_d = torch.cat([best_d, dd], 1)
-            cat_i = torch.cat([best_i, ii + s], 1)
-            sel = torch.topk(cat_d, tk, dim=1, largest=False).indices
-            best_d, best_i = torch.gather(cat_d, 1, sel), torch.gather(cat_i, 1, sel)
-            del bt, d
-        gt = best_i.cpu().numpy()
-        recall = float(np.mean([len(set(got[i, :tk]) & set(gt[i])) / tk for i in range(nq)]))
-
-    # ---------------- CPU baseline: the oracle (C restatement) on a bounded sample ---------------
-    cpu_baseline = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        from oracle import oracle as O
-        ns = min(args.cpu_sample, nq)
-        ix = O.OracleIndex(dim, preset["m"], preset["ef_construction"], 8, seed=1)
-        t0 = time.time()
-        assert ix.load_bytes(bridge.saveBytes()), "oracle rejected the engine's dump"
-        log(f"oracle loaded the dump in {time.time() - t0:.1f}s; timing {ns} queries on 1 host thread")
-        t0 = time.perf_counter()
-        o_ids, o_l2, o_n, ann_ids, ann_cnt, octr = O.search_many_db(ix, q_host[:ns], base, topk, args.preset, threads=1)
-        cpu_s = time.perf_counter() - t0
-        same = bool(np.array_equal(o_ids, got[:ns]) and
-                    np.array_equal(o_l2.view(np.uint64), l2_dev[:ns].cpu().numpy().view(np.uint64)))
-        ncores = os.cpu_count() or 1
-        nthr = min(args.build_threads, ncores)
-        t0 = time.perf_counter()
-        O.search_many_db(ix, q_host[:ns], base, topk, args.preset, threads=nthr)
-        cpu_mt_s = time.perf_counter() - t0
-        cpu_baseline = dict(value=round(ns / cpu_s, 2), unit="queries/s", cores=1, kind="port",
-                            sample=f"first {ns} of the {nq} bench queries, full searchMany pipeline on the same "
-                                   f"{N}-node dump (C restatement of the WASM path, 1 thread = the reference's "
-                                   "sequential loop)",
-                            all_cores=dict(value=round(ns / cpu_mt_s, 2), cores=nthr),
-                            gpu_matches_oracle_on_sample=same)
-        ix.close()
-
+    out = (run_scan if scan else run_hnsw)(args, torch, dist, dev, rank, world)
     if rank == 0:
-        out = dict(metric="searchMany QPS @ recall@10 (topK=10, 384-d int8+f32 rerank)",
-                   value=round(qps, 2), unit="queries/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="i8", dtype_detail="int8 rows, exact i32 distances (traversal); f32 rows, f64 accumulate (rerank)",
-                   data="synthetic",
-                   config=dict(workload=f"{N}x{dim} int8 HNSW (preset {args.preset}: M={m}, efc="
-                                        f"{preset['ef_construction']}, ef=annK={ann_k}) + f32 rerank, "
-                                        f"batch {nq} queries, topK={tk}",
-                               n=N, dim=dim, nq=nq, topk=tk, ann_k=ann_k, preset=args.preset,
-                               mode=("single" if world == 1 else args.mode),
-                               batches=("pipelined: rerank of batch i on a second stream under the traversal "
-                                        "of batch i+1" if pipelined else
-                                        f"{args.in_flight} in flight: batch i on stream i % {args.in_flight}" if interleaved
-                                        else "one at a time"),
-                               graph="engine parallel builder (reference insert algorithm, unordered)"),
-                   recall_at_10=None if recall is None else round(recall, 4),
-                   roofline=roofline, cpu_baseline=cpu_baseline,
-                   counters=dict(mean_n_dist=float(ctr[:, 0].mean()), mean_n_l0lists=float(ctr[:, 1].mean()),
-                                 mean_n_upperlists=float(ctr[:, 2].mean())))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    bridge.close()
 
 
 if __name__ == "__main__":
