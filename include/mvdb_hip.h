@@ -146,10 +146,10 @@ int mvdb_search_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 int mvdb_upload(mvdb_index *h);
 /* NO COUNTERPART IN THE REFERENCE.  mvdb_search_many_dev for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels, same outputs; the
- * per-query visited bitmaps live in a static 8 MiB device array of the library (one copy per GPU, held
+ * per-query visited bitmaps live in a static 64 MiB device array of the library (one copy per GPU, held
  * until the process ends) instead of hipMalloc'ed scratch, so the call makes no hipMalloc, hipFree or
  * event creation.  Requirements: mvdb_upload(h) since the last change of the index (else status 0);
- * nq * ceil(max_elements / 32) * 4 bytes <= 8 MiB (64 queries at 1 M nodes; else status 0 with a clear
+ * nq * round_up(ceil(max_elements / 32) * 4, 256) bytes <= 64 MiB (512 queries at 1 M nodes; else status 0 with a clear
  * text); device ordinal < 16.  Every call on one GPU shares that GPU's array: calls that overlap on one
  * GPU (any handle, any stream) race -- serialise them. */
 int mvdb_search_many_dev_noalloc(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_t *d_out_ids,

@@ -186,8 +186,8 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 // mvdb_search_many_dev_noalloc keeps its visited bitmaps here instead of in hipMalloc'ed memory.
 // `scratch` is a host-side stand-in, not a device address: host code only ever uses the per-device
 // pointer hipGetSymbolAddress returned (resolve_scratch, with that device current), as the kernel
-// argument and for hipMemsetAsync.  Every GPU the library runs on holds its own 8 MiB copy.
-constexpr size_t kNoAllocScratchBytes = (size_t)8 << 20;
+// argument and for hipMemsetAsync.  Every GPU the library runs on holds its own 64 MiB copy.
+constexpr size_t kNoAllocScratchBytes = (size_t)64 << 20;
 constexpr int kMaxDevices = 16;
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
 static void *g_scratch_ptr[kMaxDevices];
@@ -217,6 +217,9 @@ struct mvdb_index {
 		hipStream_t stream = nullptr;
 		bool used = false;
 		DevBuf visited, qf, q8, ids, dist, cnt;
+		void *vis_seen_ptr = nullptr;  // the allocation (pointer, capacity) `vis_epoch` counts launches of
+		size_t vis_seen_cap = 0;
+		unsigned vis_epoch = 0;        // stamp of the last launch on `visited` (VisitedSet): 1..255
 	} ss[kStreamSets];
 	int ss_next = 0;  // round-robin victim when every set is taken
 	DevBuf st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
@@ -804,7 +807,8 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	a.cand_cap = cand_cap;
 	a.results_cap = h->g.results_cap;
 	a.set_only = set_only ? 1 : 0;
-	a.vis_words = ((size_t)h->g.max_elements + 31) / 32;
+	a.vis_stride = visited_stride_bytes(h->g.max_elements);
+	a.epoch = 1;
 }
 
 mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
@@ -843,19 +847,27 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	}
 	TraverseArgs a;
 	traverse_params(h, k, a, set_only);
-	// visited bitmaps: bounded scratch, queries are processed in slabs
-	const size_t slab_bytes_max = (size_t)2 << 30;
-	int slab = (int)std::min<size_t>((size_t)nq, std::max<size_t>(1, slab_bytes_max / (a.vis_words * 4)));
+	// visited sets: bounded scratch per stream, queries are processed in slabs beyond it
+	const size_t slab_bytes_max = (size_t)16 << 30;
+	int slab = (int)std::min<size_t>((size_t)nq, std::max<size_t>(1, slab_bytes_max / a.vis_stride));
 	mvdb_index::StreamScratch *sc = scratch_for(h, s);
 	if (!sc) return 0;
-	uint32_t *vis = static_cast<uint32_t *>(sc->visited.need((size_t)slab * a.vis_words * 4));
+	void *vis = sc->visited.need((size_t)slab * a.vis_stride);
 	if (!vis) {
-		h->set_error("out of device memory (visited bitmaps)");
+		h->set_error("out of device memory (visited sets)");
 		return 0;
 	}
 	for (int q0 = 0; q0 < nq; q0 += slab) {
 		const int n = std::min(slab, nq - q0);
-		HIP_OK(h, hipMemsetAsync(vis, 0, (size_t)n * a.vis_words * 4, s));
+		// a fresh allocation, or the epoch wrapping after 255 launches, clears the whole buffer; otherwise the
+		// next epoch makes every stamp of earlier launches read as "not visited" (nothing to clear per batch)
+		if (!MVDB_VISITED_STAMPS || sc->vis_seen_ptr != vis || sc->vis_seen_cap != sc->visited.cap || sc->vis_epoch >= 255) {
+			HIP_OK(h, hipMemsetAsync(vis, 0, MVDB_VISITED_STAMPS ? sc->visited.cap : (size_t)n * a.vis_stride, s));
+			sc->vis_seen_ptr = vis;
+			sc->vis_seen_cap = sc->visited.cap;
+			sc->vis_epoch = 0;
+		}
+		a.epoch = ++sc->vis_epoch;
 		StageTimer t(h, 1, s);  // brackets the traversal kernel only
 		a.q = d_q + (size_t)q0 * g.cfg.dim;
 		a.nq = n;
@@ -868,7 +880,7 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		a.err = h->err_dev;
 		a.inject_abort_q = h->inject_abort_q >= q0 && h->inject_abort_q < q0 + n ? h->inject_abort_q - q0 : -1;
 #ifdef MVDB_TRAVERSE_PROFILE
-		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * 192)) + (size_t)q0 * 24;
+		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * kProfSlots * 8)) + (size_t)q0 * kProfSlots;
 #endif
 		if (!launch_traverse(h, a, s)) return 0;
 	}
@@ -942,14 +954,15 @@ int mvdb_search_many_dev_noalloc(mvdb_index *h, const int8_t *d_q, int nq, int k
 	}
 	TraverseArgs a;
 	traverse_params(h, k, a, false);
-	const size_t need = (size_t)nq * a.vis_words * 4;
+	const size_t need = (size_t)nq * a.vis_stride;
 	if (need > kNoAllocScratchBytes) {
-		h->set_error("mvdb_search_many_dev_noalloc: nq * ceil(max_elements / 32) * 4 bytes of visited bitmaps exceed the "
-		             "8 MiB static scratch (e.g. 64 queries at 1 M nodes); use mvdb_search_many_dev");
+		h->set_error("mvdb_search_many_dev_noalloc: the visited sets of nq queries (nq * ceil(max_elements / 32) * 4 bytes, rows "
+		             "padded to 256) exceed the 64 MiB static scratch (512 queries at 1 M nodes); use mvdb_search_many_dev");
 		return 0;
 	}
-	uint32_t *vis = static_cast<uint32_t *>(g_scratch_ptr[d]);  // never the array's name: that is not a device address
-	HIP_OK(h, hipMemsetAsync(vis, 0, need, s));                 // the array keeps the last call's bits
+	void *vis = g_scratch_ptr[d];                // never the array's name: that is not a device address
+	HIP_OK(h, hipMemsetAsync(vis, 0, need, s));  // the array keeps the last call's bits: cleared every call
+	a.epoch = 1;
 	a.q = d_q;
 	a.nq = nq;
 	a.visited = vis;
@@ -1336,7 +1349,7 @@ int mvdb_debug_scan_counters(mvdb_index *h, unsigned long long *out)
 int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 {
 	if (!h->prof_buf.p) return 0;
-	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * 192, hipMemcpyDeviceToHost) == hipSuccess;
+	return hipMemcpy(out, h->prof_buf.p, (size_t)nq * kProfSlots * 8, hipMemcpyDeviceToHost) == hipSuccess;
 }
 #endif
 int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)

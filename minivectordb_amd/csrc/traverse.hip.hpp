@@ -51,6 +51,55 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
 typedef __attribute__((address_space(3))) u32x2_t lds_u32x2;
 
+// ---- visited set of one query (hnsw.ts:118-132, :494-495) -------------------------------------
+// Default (MVDB_VISITED_STAMPS=0): a private bitmap per query in global memory, test-and-set by ONE returning
+// atomicOr per listed neighbour, issued together with its row; zeroed by the launcher per batch.  On gfx950 these
+// atomics execute at the memory side (TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r2/pmc_traffic_1m_balanced.json): they
+// are ~27 % of the kernel's HBM-side requests on top of the algorithmic bytes.
+// MVDB_VISITED_STAMPS=1 is the reference's own scheme (a stamp per node, bumped per search) with one BYTE per node:
+// visited iff the byte equals the launch's epoch, so nothing is cleared between launches (the launcher zeroes the
+// slice when the epoch wraps after 255 launches); test = one L1-bypassing byte load, set = one plain store
+// (distinct ids, distinct bytes: no atomics).  Bit-exact like the bitmap (the whole GPU suite passes), but SLOWER
+// on MI355X at 1M x 384, ef 1200: 3.03 vs 2.67 ms per 1k-query launch alone, 375 k vs 405 k queries/s with three
+// batches in flight -- two scattered one-byte requests per neighbour cost more than one atomic.  Kept for A/B runs.
+#ifndef MVDB_VISITED_STAMPS
+#define MVDB_VISITED_STAMPS 0
+#endif
+struct VisitedSet {
+#if MVDB_VISITED_STAMPS
+	uint8_t *p;
+	unsigned epoch;
+	__device__ __forceinline__ unsigned probe(int id) const
+	{
+		return __hip_atomic_load(p + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__device__ __forceinline__ bool seen(unsigned probed, int) const { return probed == epoch; }
+	__device__ __forceinline__ void set(int id) const { p[id] = (uint8_t)epoch; }
+#else
+	uint32_t *p;
+	unsigned epoch;
+	__device__ __forceinline__ unsigned probe(int id) const { return atomicOr(&p[(unsigned)id >> 5], 1u << (id & 31)); }
+	__device__ __forceinline__ bool seen(unsigned probed, int id) const { return (probed >> (id & 31)) & 1u; }
+	__device__ __forceinline__ void set(int) const {}
+#endif
+	__device__ __forceinline__ void mark(int id) const  // the entry point (:452)
+	{
+#if MVDB_VISITED_STAMPS
+		p[id] = (uint8_t)epoch;
+#else
+		atomicOr(&p[(unsigned)id >> 5], 1u << (id & 31));
+#endif
+	}
+};
+__host__ __device__ inline size_t visited_stride_bytes(int max_elements)
+{
+#if MVDB_VISITED_STAMPS
+	return ((size_t)max_elements + 255) & ~(size_t)255;
+#else
+	return (((size_t)max_elements + 31) / 32 * 4 + 255) & ~(size_t)255;
+#endif
+}
+
 // ---- 1-based array heaps in LDS ------------------------------------------------
 // MIN = candidate min-heap (hnsw.ts:153-213), !MIN = result max-heap (:233-315).
 // Entry p = {key, id} (8 bytes); children 2p, 2p+1 are one aligned 16-byte LDS read.
@@ -327,8 +376,9 @@ struct TraverseArgs {
 	const int8_t *q;      // nq x dim packed
 	int nq, k, ef, cand_cap, results_cap;
 	int set_only;         // 1: the caller only needs the SET of candidates (see traverse_emit_unsorted)
-	uint32_t *visited;    // nq x vis_words, zeroed by the launcher
-	size_t vis_words;
+	void *visited;        // nq x vis_stride bytes, see VisitedSet
+	size_t vis_stride;    // bytes per query
+	unsigned epoch;       // stamp of this launch (1..255) when MVDB_VISITED_STAMPS
 	int32_t *out_ids;     // nq x k
 	float *out_dist;      // nq x k
 	int32_t *out_count;   // nq
@@ -361,6 +411,7 @@ __device__ __forceinline__ void traverse_report_abort(const TraverseArgs &a, int
 	}
 }
 
+constexpr int kProfSlots = 32;  // u64 cycle sums per query in diagnostic builds
 #ifdef MVDB_TRAVERSE_PROFILE
 #define MVDB_STAMP(slot)                                        \
 	do {                                                        \
@@ -468,13 +519,13 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 
 	MVDB_STAMP(0);  // query load + descent
 	// search_layer(query, cur, 0, ef, false): hnsw.ts:423-523
-	uint32_t *vis = a.visited + (size_t)qi * a.vis_words;
+	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride), a.epoch};
 	int cand_size = 0, res_size = 0;
 	{
 		// dist0 (:450) re-evaluates the row the descent ended on: same value, counted, not re-read
 		const unsigned d0 = cur_d;
 		n_dist++;
-		if (lane == 0) atomicOr(&vis[(unsigned)cur >> 5], 1u << (cur & 31));  // :452
+		if (lane == 0) vis.mark(cur);  // :452
 		cand.push(cand_size++, cur, d0, lane);                                 // :453
 		res.push(res_size++, cur, d0, lane);                                   // :454
 	}
@@ -513,13 +564,11 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 			if (base + lane < ix.m0) nb = lst[base + lane];
 			background(6);
 			bool isnew = false;
-			uint32_t old = 0, bit = 0;
-			if (nb >= 0) {  // :494-495 visited test-and-set
-				bit = 1u << (nb & 31);
-				old = atomicOr(&vis[(unsigned)nb >> 5], bit);
-			}
+			unsigned old = 0;
+			if (nb >= 0) old = vis.probe(nb);  // :494-495 visited test-and-set
 			background(6);
-			isnew = nb >= 0 && !(old & bit);
+			isnew = nb >= 0 && !vis.seen(old, nb);
+			if (isnew) vis.set(nb);
 			const unsigned long long nm = __ballot(isnew);
 			const int n = __builtin_popcountll(nm);
 			MVDB_STAMP(2);  // neighbour list + visited test-and-set
@@ -600,7 +649,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 #ifdef MVDB_TRAVERSE_PROFILE
 	MVDB_STAMP(6);  // output
 	if (lane == 0 && a.prof)
-		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * 24 + i] = prof_acc[i];
+		for (int i = 0; i < 8; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
 #endif
 	if (lane == 0) {
 		a.out_count[qi] = out_count;

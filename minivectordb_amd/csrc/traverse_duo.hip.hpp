@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 	static_assert(WAVES == 2 || WAVES == 3, "two or three waves per query");
 	constexpr bool TRIO = WAVES == 3;
 #ifdef MVDB_TRAVERSE_PROFILE
-	unsigned long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long prof_acc[kProfSlots] = {};
 	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 	unsigned long long prof_unsure = 0, prof_admitted = 0;
 #endif
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 	const DevIndexView &ix = a.ix;
 #ifdef MVDB_TRAVERSE_PROFILE
 	// where the hardware put this wave: HW_ID bits [5:4] = SIMD, [11:8] = CU, [15:13] = SE (slots 20..22)
-	if (lane == 0 && a.prof) a.prof[(size_t)qi * 24 + 20 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+	if (lane == 0 && a.prof) a.prof[(size_t)qi * kProfSlots + 20 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
 #endif
 
 	const int ef = a.ef, cand_cap = a.cand_cap;
@@ -256,10 +256,10 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 
 		MVDB_DUO_STAMP(0);
 		// search_layer(query, cur, 0, ef, false): :450-454
-		uint32_t *vis = a.visited + (size_t)qi * a.vis_words;
+		const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride), a.epoch};
 		int cand_size = 0;
 		n_dist++;  // dist0 (:450) re-evaluates the row the descent ended on
-		if (lane == 0) atomicOr(&vis[(unsigned)cur >> 5], 1u << (cur & 31));
+		if (lane == 0) vis.mark(cur);
 		cand.push(cand_size++, cur, cur_d, lane);
 		duo_publish(&sy->record[0], u32x4_t{1u, (unsigned)kRecInit, (unsigned)cur, cur_d}, lane);
 
@@ -300,16 +300,16 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 			const int cnt = __builtin_popcountll(__ballot(nb >= 0));  // canonical lists: valid prefix
 			MVDB_DUO_STAMP(10);
 			if (cnt == 0) return 0;
-			uint32_t old = 0, bit = 0;
+			unsigned old = 0;
 			if (nb >= 0) {  // :494-495
-				bit = 1u << (nb & 31);
-				old = atomicOr(&vis[(unsigned)nb >> 5], bit);
+				old = vis.probe(nb);
 				if (MVDB_DUO_SPEC_ROWS) all_ids[lane] = nb;
 			}
 			if (!MVDB_DUO_SPEC_ROWS) {
 				// rows of the NEW neighbours only, after the visited words are back
 				background(6);
-				const bool isnew = nb >= 0 && !(old & bit);
+				const bool isnew = nb >= 0 && !vis.seen(old, nb);
+				if (isnew) vis.set(nb);
 				const unsigned long long nm = __ballot(isnew);
 				const int n = __builtin_popcountll(nm);
 				if (n == 0) return 0;
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 			if (cnt > 32) pass(32, false);
 			MVDB_DUO_STAMP(13);
 			sink ^= warm;
-			const bool isnew = nb >= 0 && !(old & bit);
+			const bool isnew = nb >= 0 && !vis.seen(old, nb);
+			if (isnew) vis.set(nb);
 			const unsigned long long nm = __ballot(isnew);
 			const int n = __builtin_popcountll(nm);
 			if (isnew) {
@@ -532,9 +533,9 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 #ifdef MVDB_TRAVERSE_PROFILE
 		MVDB_DUO_STAMP(4);
 		if (lane == 0 && a.prof) {
-			for (int i = 0; i < 5; i++) a.prof[(size_t)qi * 24 + i] = prof_acc[i];
-			for (int i = 10; i < 15; i++) a.prof[(size_t)qi * 24 + i] = prof_acc[i];
-			a.prof[(size_t)qi * 24 + 8] = prof_unsure;
+			for (int i = 0; i < 5; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
+			for (int i = 10; i < 15; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
+			a.prof[(size_t)qi * kProfSlots + 8] = prof_unsure;
 		}
 #endif
 		cpipe.drain();
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 			if (kind == kRecEnd) {
 #ifdef MVDB_TRAVERSE_PROFILE
 				if (lane == 0 && a.prof)
-					for (int i = 16; i < 20; i++) a.prof[(size_t)qi * 24 + i] = prof_acc[i];
+					for (int i = 16; i < 20; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
 #endif
 				return;
 			}
@@ -785,9 +786,9 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 #ifdef MVDB_TRAVERSE_PROFILE
 	MVDB_DUO_STAMP(7);
 	if (lane == 0 && a.prof) {
-		for (int i = 5; i < 8; i++) a.prof[(size_t)qi * 24 + i] = prof_acc[i];
-		a.prof[(size_t)qi * 24 + 15] = prof_acc[15];
-		a.prof[(size_t)qi * 24 + 9] = prof_admitted;
+		for (int i = 5; i < 8; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
+		a.prof[(size_t)qi * kProfSlots + 15] = prof_acc[15];
+		a.prof[(size_t)qi * kProfSlots + 9] = prof_admitted;
 	}
 #endif
 	int out_count = found < a.k ? found : a.k;  // :1015-1017

@@ -59,10 +59,10 @@ def test_noalloc_equals_search_many_dev(gpu):
         assert np.array_equal(dist_a.view(np.uint32), od.view(np.uint32))
     assert L.mvdb_check_errors(b.handle) == 1
 
-    # beyond the static scratch: 4000 nodes -> 500 B of bitmap per query -> 16777 queries fit, 20000 do not
-    too_many = torch.zeros((20000, 384), dtype=torch.int8, device=dev)
-    ok, *_ = _call(L.mvdb_search_many_dev_noalloc, b, too_many, 20000, 10, torch, dev)
-    assert ok == 0 and b"8 MiB" in L.mvdb_last_error(b.handle)
+    # beyond the static scratch: 4000 nodes -> 512 B of bitmap per query -> 131072 queries fit, 140000 do not
+    too_many = torch.zeros((140000, 384), dtype=torch.int8, device=dev)
+    ok, *_ = _call(L.mvdb_search_many_dev_noalloc, b, too_many, 140000, 1, torch, dev)
+    assert ok == 0 and b"64 MiB" in L.mvdb_last_error(b.handle)
     # a change of the index needs a new mvdb_upload
     b.insertManyPacked(np.array([5], np.int32), b8[6], 384)
     ok, *_ = _call(L.mvdb_search_many_dev_noalloc, b, qd, 37, 300, torch, dev)

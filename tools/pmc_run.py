@@ -1,6 +1,7 @@
 """Workload for the rocprofv3 --pmc passes (HBM traffic of the traversal kernel).
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_run.py
+  (tools/pmc_passes.sh runs every pass; tools/pmc_parse2.py turns them into profiles/rN/pmc_traffic_*.json)
 
 Launches, on one 1M x 384 balanced index: (1) a calibration launch of dist_pairs_kernel whose byte
 count is known exactly (it gathers rows with the same 8-lanes-x-16-B pattern as the traversal), then
@@ -20,7 +21,7 @@ base8 = np.empty((n, dim), np.int8)
 for s in range(0, n, 131072):
     _, q8 = b.prepareQueries(rng.standard_normal((min(131072, n - s), dim), dtype=np.float32))
     base8[s:s + 131072] = q8
-t0 = time.time(); b.buildParallel(base8, 16); print("built in", time.time() - t0, flush=True)
+t0 = time.time(); b.buildGpu(base8); print("built in", time.time() - t0, flush=True)
 q = np.random.default_rng(54321).standard_normal((nq, dim), dtype=np.float32)
 _, qi8 = b.prepareQueries(q)
 per_q = 18000

@@ -26,20 +26,22 @@ if __name__ == "__main__":
     base = rng.standard_normal((n, dim), dtype=np.float32)
     b = HipBridge(); b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], capacity=n, seed=42, resultsCap=4096))
     qn, q8 = b.prepareQueries(base)
-    b.buildParallel(q8, 16)
+    b.buildGpu(q8)
+    waves = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    b.setTuning(traverse_waves=waves)
     q = np.random.default_rng(54321).standard_normal((nq, dim), dtype=np.float32)
     _, qi8 = b.prepareQueries(q)
     tk, ef, ann_k = derive_search_params(10, p)
     b.setEfSearch(ef)
     for _ in range(3):
         t0 = time.perf_counter(); ids, dist, cnt, ctr = b.searchManyArrays(qi8, ann_k, with_counters=True); t1 = time.perf_counter()
-    prof = np.zeros((nq, 24), np.uint64)
+    prof = np.zeros((nq, 32), np.uint64)
     L = b._L
     L.mvdb_debug_traverse_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     assert L.mvdb_debug_traverse_profile(b.handle, prof.ctypes.data_as(C.c_void_p), nq)
     print(f"host wall of searchMany (incl. copies): {(t1 - t0) * 1e3:.2f} ms")
     print("counters mean:", ctr.mean(0))
-    if os.environ.get("MVDB_TRAVERSE_WAVES") == "1":
+    if waves == 1:
         names = ["descent", "cand_pop", "list+visited", "rows+dist", "heap_updates", "final_sort", "output"]
         print("admitted neighbours per query (mean):", prof[:, 7].mean())
         tot = prof[:, :7].sum(1).astype(np.float64)
@@ -49,7 +51,7 @@ if __name__ == "__main__":
     else:
         acc = ["descent", "early_mem", "wait_adm+replay", "late_mem", "pop+publish+predict"]
         resw = ["wait_record", "admission", "final_sort"]
-        print(f"  R cand pushes + wait sift {prof[:, 15].mean():12.0f} cyc")
+        print(f"  R cand pushes + wait sift (2 waves) {prof[:, 15].mean():12.0f} cyc")
         for i, nm in zip(range(16, 20), ["wait message", "wait sift_req", "sift-down", "pushes"]):
             print(f"  P {nm:20s} {prof[:, i].mean():12.0f} cyc")
         for i, nm in zip(range(10, 15), ["mem:list", "mem:issue", "mem:background", "mem:rows+dist", "mem:compact"]):

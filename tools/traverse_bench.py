@@ -48,7 +48,7 @@ def main():
     if dump and os.path.exists(dump):
         b.load(dump)
     else:
-        b.buildParallel(b8, threads)
+        b.buildGpu(b8)
         if dump:
             b.save(dump)
     stop.set()
