@@ -100,8 +100,10 @@ size_t mvdb_dump_size(const mvdb_index *h);
 size_t mvdb_save_dump(const mvdb_index *h, uint8_t *buf);
 
 /* ---- write path on the host graph (assembly/hnsw.ts:719-953) -------------- */
-/* insert (upsert) / WasmBridge.insertManyPacked (wasm-bridge.ts:268-288).  The
- * graph is edited on the host and re-uploaded lazily before the next search. */
+/* insert (upsert) / WasmBridge.insertManyPacked (wasm-bridge.ts:268-288).  The graph is
+ * edited on the host; before the next search only the rows of the touched nodes (int8 row,
+ * layer-0 list, upper lists) are re-derived and patched into the device mirror, so an oplog
+ * replay (src/mini-vector-db.ts:1544-1587) costs O(changed nodes), not a re-upload. */
 int mvdb_insert_many(mvdb_index *h, const int32_t *ids, const int8_t *packed, int n);
 /* update_vector (hnsw.ts:837) */
 int mvdb_update_vector(mvdb_index *h, int id, const int8_t *vec);
@@ -227,6 +229,8 @@ int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves);
  * The WASM cannot fail this way; the reference's nearest analogue is the abort import
  * that only logs (wasm-bridge.ts:57-59). */
 int mvdb_check_errors(mvdb_index *h);
+/* Device-mirror traffic since mvdb_create: out3 = {full uploads, incremental patches, nodes patched}. */
+void mvdb_upload_counters(const mvdb_index *h, long long *out3);
 /* Test hook: query index `query` of every following traversal launch takes the abort
  * path (-1 = off). */
 void mvdb_debug_inject_abort(mvdb_index *h, int query);

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("mvdb_merge_topk_packed_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_set_tuning", _i, [_vp, _i, _i]),
     ("mvdb_check_errors", _i, [_vp]),
+    ("mvdb_upload_counters", None, [_vp, _vp]),
     ("mvdb_debug_inject_abort", None, [_vp, _i]),
     ("mvdb_release_stream", _i, [_vp, _vp]),
     ("mvdb_enable_timing", None, [_vp, _i]),

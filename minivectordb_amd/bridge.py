@@ -123,6 +123,12 @@ class HipBridge:
         with self._lock:
             self._check(self._L.mvdb_check_errors(self.handle))
 
+    def uploadCounters(self) -> dict:
+        """Device-mirror traffic of this handle: full uploads, incremental patches, nodes patched."""
+        out = (C.c_longlong * 3)()
+        self._L.mvdb_upload_counters(self.handle, out)
+        return dict(full_uploads=out[0], patches=out[1], nodes_patched=out[2])
+
     def _dim(self) -> int:
         return int(self._cfg["dim"])
 

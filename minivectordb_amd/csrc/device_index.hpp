@@ -21,6 +21,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "host_graph.hpp"
 
@@ -44,10 +45,24 @@ public:
 	~DeviceIndex() { release(); }
 	// (re)build from the host graph; returns false and sets err on HIP failure
 	bool upload(const HostGraph &g, std::string &err);
+	// Incremental update (reference insert / update_and_reconnect, hnsw.ts:719-953, leave the rest
+	// of the WASM memory untouched too): re-derive and overwrite only the rows of g.dirty -- int8 row, norm, canonical
+	// layer-0 list, upper lists -- and append the upper lists of new nodes.  Returns 1 = patched, 0 = not possible
+	// (caller falls back to upload: capacity changed, list slack exhausted, or a new id that an untouched list of a
+	// foreign dump may already name), -1 = HIP failure (err set).
+	int patch(const HostGraph &g, std::string &err);
 	void release();
+	long long full_uploads = 0, patches = 0, nodes_patched = 0;
 
 private:
 	void *d_vec_ = nullptr, *d_adj0_ = nullptr, *d_upper_ = nullptr, *d_norm2_ = nullptr;
+	// host-side bookkeeping of the mirror
+	std::vector<int32_t> code_;      // per node: (index of its layer-1 list << 2) | level, as uploaded
+	std::vector<int8_t> dev_level_;  // level as uploaded, -1 = absent on the device
+	int64_t n_lists_ = 0, cap_lists_ = 0;
+	bool has_dangling_ = false;      // some list names an in-range id that is absent: its canonical form depends on presence
+	void canon_adj0(const HostGraph &g, int i, int32_t *dst);
+	void canon_upper(const HostGraph &g, int i, int l, int2 *dst);
 };
 
 }  // namespace mvdb

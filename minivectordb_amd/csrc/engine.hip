@@ -71,6 +71,44 @@ void DeviceIndex::release()
 	norm2 = nullptr;
 	view = DevIndexView{};
 	built_version = ~0ull;
+	code_.clear();
+	dev_level_.clear();
+	n_lists_ = cap_lists_ = 0;
+	has_dangling_ = false;
+}
+
+// layer-0 list of node i as the device holds it (see device_index.hpp): ids the reference scan would not skip
+void DeviceIndex::canon_adj0(const HostGraph &g, int i, int32_t *dst)
+{
+	const int m0 = g.cfg.m0();
+	std::fill_n(dst, m0, -1);
+	if (g.level[i] < 0) return;
+	const int32_t *src = g.adj0.data() + (size_t)i * m0;
+	const int cnt = std::clamp(g.cnt0[i], 0, m0);
+	int w = 0;
+	for (int j = 0; j < cnt; j++) {
+		const int nb = src[j];
+		if (nb >= 0 && nb < g.max_elements && g.level[nb] < 0) has_dangling_ = true;
+		if (!g.present(nb) || nb == i) continue;
+		if (std::find(dst, dst + w, nb) != dst + w) continue;
+		dst[w++] = nb;
+	}
+}
+
+// upper list l (>= 1) of node i as (id, code) pairs
+void DeviceIndex::canon_upper(const HostGraph &g, int i, int l, int2 *dst)
+{
+	const int m = g.cfg.m;
+	std::fill_n(dst, m, make_int2(-1, -1));
+	const int32_t *rec = g.upper.data() + g.upper_off[i] + (size_t)(l - 1) * (1 + m);
+	const int cnt = std::clamp(rec[0], 0, m);
+	int w = 0;
+	for (int j = 0; j < cnt; j++) {
+		const int nb = rec[1 + j];
+		if (nb >= 0 && nb < g.max_elements && g.level[nb] < 0) has_dangling_ = true;
+		if (!g.present(nb)) continue;
+		dst[w++] = make_int2(nb, code_[nb]);
+	}
 }
 
 bool DeviceIndex::upload(const HostGraph &g, std::string &err)
@@ -87,22 +125,26 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 	view.max_level = g.max_level;
 	view.entry_code = 0;
 	built_version = g.version;
+	full_uploads++;
 	if (N <= 0) return true;
 
-	// cum[id] = index of the node's layer-1 list among all upper lists
-	std::vector<int32_t> code((size_t)N, 0);
-	int64_t n_lists = 0;
+	// code[id] = (index of the node's layer-1 list among all upper lists << 2) | level
+	code_.assign((size_t)N, 0);
+	dev_level_.assign(g.level.begin(), g.level.begin() + N);
+	n_lists_ = 0;
 	for (int i = 0; i < N; i++) {
 		const int lvl = g.level[i];
 		if (lvl < 0) continue;
-		if (n_lists > (int64_t)0x1fffffff) {
+		if (n_lists_ > (int64_t)0x1fffffff) {
 			err = "too many upper-layer lists for the 29-bit list index";
 			return false;
 		}
-		code[i] = (int32_t)((n_lists << 2) | lvl);
-		n_lists += lvl;
+		code_[i] = (int32_t)((n_lists_ << 2) | lvl);
+		n_lists_ += lvl;
 	}
-	if (g.present(g.entry_point)) view.entry_code = code[g.entry_point];
+	// room for the upper lists of nodes inserted later (DeviceIndex::patch appends)
+	cap_lists_ = std::min<int64_t>(n_lists_ + std::max<int64_t>(4096, n_lists_ / 8), (int64_t)0x1fffffff);
+	if (g.present(g.entry_point)) view.entry_code = code_[g.entry_point];
 
 	auto check = [&](hipError_t e, const char *what) {
 		if (e == hipSuccess) return true;
@@ -133,53 +175,131 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 
 	// layer 0, canonicalised (see device_index.hpp)
 	{
-		std::vector<int32_t> adj((size_t)N * m0, -1);
-		for (int i = 0; i < N; i++) {
-			if (g.level[i] < 0) continue;
-			const int32_t *src = g.adj0.data() + (size_t)i * m0;
-			int32_t *dst = adj.data() + (size_t)i * m0;
-			const int cnt = std::clamp(g.cnt0[i], 0, m0);
-			int w = 0;
-			for (int j = 0; j < cnt; j++) {
-				const int nb = src[j];
-				if (!g.present(nb) || nb == i) continue;
-				if (std::find(dst, dst + w, nb) != dst + w) continue;
-				dst[w++] = nb;
-			}
-		}
+		std::vector<int32_t> adj((size_t)N * m0);
+		for (int i = 0; i < N; i++) canon_adj0(g, i, adj.data() + (size_t)i * m0);
 		bytes_adj0 = adj.size() * 4;
 		if (!check(hipMalloc(&d_adj0_, std::max<size_t>(bytes_adj0, 256)), "hipMalloc(adj0)")) return false;
 		if (!check(hipMemcpy(d_adj0_, adj.data(), bytes_adj0, hipMemcpyHostToDevice), "copy adj0")) return false;
 	}
 	// upper layers as (id, code) pairs
 	{
-		std::vector<int2> up((size_t)n_lists * m, make_int2(-1, -1));
+		std::vector<int2> up((size_t)n_lists_ * m, make_int2(-1, -1));
 		for (int i = 0; i < N; i++) {
 			const int lvl = g.level[i];
 			if (lvl < 1) continue;
-			const int64_t cum = code[i] >> 2;
-			for (int l = 1; l <= lvl; l++) {
-				const int32_t *rec = g.upper.data() + g.upper_off[i] + (size_t)(l - 1) * (1 + m);
-				const int cnt = std::clamp(rec[0], 0, m);
-				int2 *dst = up.data() + (size_t)(cum + l - 1) * m;
-				int w = 0;
-				for (int j = 0; j < cnt; j++) {
-					const int nb = rec[1 + j];
-					if (!g.present(nb)) continue;
-					dst[w++] = make_int2(nb, code[nb]);
-				}
-			}
+			const int64_t cum = code_[i] >> 2;
+			for (int l = 1; l <= lvl; l++) canon_upper(g, i, l, up.data() + (size_t)(cum + l - 1) * m);
 		}
-		bytes_upper = up.size() * sizeof(int2);
+		bytes_upper = (size_t)cap_lists_ * m * sizeof(int2);
 		if (!check(hipMalloc(&d_upper_, std::max<size_t>(bytes_upper, 256)), "hipMalloc(upper)")) return false;
-		if (bytes_upper &&
-		    !check(hipMemcpy(d_upper_, up.data(), bytes_upper, hipMemcpyHostToDevice), "copy upper"))
+		if (!up.empty() &&
+		    !check(hipMemcpy(d_upper_, up.data(), up.size() * sizeof(int2), hipMemcpyHostToDevice), "copy upper"))
 			return false;
 	}
 	view.vec = static_cast<const int8_t *>(d_vec_);
 	view.adj0 = static_cast<const int32_t *>(d_adj0_);
 	view.upper = static_cast<const int2 *>(d_upper_);
 	return true;
+}
+
+namespace {
+// dst row idx[r] <- src row r, rows of row_bytes (a multiple of 4)
+__global__ void scatter_rows_kernel(unsigned *dst, size_t row_words, const int32_t *idx, const unsigned *src, int n)
+{
+	const int r = blockIdx.x;
+	if (r >= n) return;
+	unsigned *d = dst + (size_t)idx[r] * row_words;
+	const unsigned *s = src + (size_t)r * row_words;
+	for (size_t i = threadIdx.x; i < row_words; i += blockDim.x) d[i] = s[i];
+}
+}  // namespace
+
+int DeviceIndex::patch(const HostGraph &g, std::string &err)
+{
+	const int N = g.max_elements, dim = g.cfg.dim, m = g.cfg.m, m0 = g.cfg.m0();
+	if (g.dirty_all || built_version != g.dirty_base || N != view.max_elements || N <= 0 || !d_vec_) return 0;
+	const size_t nd = g.dirty.size();
+	if (nd == 0) {
+		built_version = g.version;
+		return 1;
+	}
+	if (nd > (size_t)N / 4) return 0;  // a full upload is cheaper
+	const int stride = view.row_stride;
+	// new nodes first: their codes are named by the lists of the other dirty nodes
+	for (int id : g.dirty) {
+		const int lvl = g.level[id];
+		if (lvl < 0) return 0;  // nodes never disappear (no delete in the ANN index)
+		if (dev_level_[id] >= 0) {
+			if (dev_level_[id] != lvl) return 0;  // a re-created node: not an edit of the mirror
+			continue;
+		}
+		if (has_dangling_) return 0;  // an untouched list may name this id: its canonical form changes with presence
+		if (n_lists_ + lvl > cap_lists_) return 0;
+	}
+	for (int id : g.dirty) {
+		if (dev_level_[id] >= 0) continue;
+		const int lvl = g.level[id];
+		code_[id] = (int32_t)((n_lists_ << 2) | lvl);
+		n_lists_ += lvl;
+		dev_level_[id] = (int8_t)lvl;
+	}
+	// staging: one row of each array per dirty node, one row per upper list
+	std::vector<int32_t> ids(g.dirty.begin(), g.dirty.end());
+	std::vector<int8_t> vrows(nd * stride, 0);
+	std::vector<int32_t> n2(nd), arows(nd * m0), lidx;
+	std::vector<int2> urows;
+	for (size_t r = 0; r < nd; r++) {
+		const int id = ids[r];
+		std::memcpy(vrows.data() + r * stride, g.row(id), (size_t)dim);
+		n2[r] = dot_i8(g.row(id), g.row(id), dim);
+		canon_adj0(g, id, arows.data() + r * m0);
+		const int64_t cum = code_[id] >> 2;
+		for (int l = 1; l <= g.level[id]; l++) {
+			lidx.push_back((int32_t)(cum + l - 1));
+			urows.resize(urows.size() + m);
+			canon_upper(g, id, l, urows.data() + urows.size() - m);
+		}
+	}
+	if (has_dangling_) return 0;  // a patched list itself names an absent id now: rebuild with the flag set
+	auto fail = [&](hipError_t e, const char *what) {
+		err = std::string(what) + ": " + hipGetErrorString(e);
+		return -1;
+	};
+	const size_t b_ids = nd * 4, b_v = vrows.size(), b_n2 = nd * 4, b_a = arows.size() * 4, b_li = lidx.size() * 4,
+	             b_u = urows.size() * sizeof(int2);
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t o_v = al(b_ids), o_n2 = o_v + al(b_v), o_a = o_n2 + al(b_n2), o_li = o_a + al(b_a), o_u = o_li + al(b_li);
+	unsigned char *stg = nullptr;
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(&stg), o_u + al(b_u) + 256);
+	if (e != hipSuccess) return fail(e, "hipMalloc(patch staging)");
+	auto put = [&](size_t off, const void *p, size_t n) { return n ? hipMemcpy(stg + off, p, n, hipMemcpyHostToDevice) : hipSuccess; };
+	if ((e = put(0, ids.data(), b_ids)) != hipSuccess || (e = put(o_v, vrows.data(), b_v)) != hipSuccess ||
+	    (e = put(o_n2, n2.data(), b_n2)) != hipSuccess || (e = put(o_a, arows.data(), b_a)) != hipSuccess ||
+	    (e = put(o_li, lidx.data(), b_li)) != hipSuccess || (e = put(o_u, urows.data(), b_u)) != hipSuccess) {
+		(void)hipFree(stg);
+		return fail(e, "copy patch staging");
+	}
+	const int32_t *d_ids = reinterpret_cast<const int32_t *>(stg);
+	auto scatter = [&](void *dst, size_t row_bytes, const int32_t *idx, size_t off, size_t n) {
+		if (n == 0) return;
+		hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)n), dim3(64), 0, nullptr, static_cast<unsigned *>(dst), row_bytes / 4,
+		                   idx, reinterpret_cast<const unsigned *>(stg + off), (int)n);
+	};
+	scatter(d_vec_, (size_t)stride, d_ids, o_v, nd);
+	scatter(d_norm2_, 4, d_ids, o_n2, nd);
+	scatter(d_adj0_, (size_t)m0 * 4, d_ids, o_a, nd);
+	scatter(d_upper_, (size_t)m * sizeof(int2), reinterpret_cast<const int32_t *>(stg + o_li), o_u, lidx.size());
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipDeviceSynchronize();
+	(void)hipFree(stg);
+	if (e != hipSuccess) return fail(e, "patch kernels");
+	view.entry = g.entry_point;
+	view.max_level = g.max_level;
+	view.entry_code = g.present(g.entry_point) ? code_[g.entry_point] : 0;
+	built_version = g.version;
+	patches++;
+	nodes_patched += (long long)nd;
+	return 1;
 }
 
 // --------------------------------------------------------------------------- no-allocation scratch
@@ -325,10 +445,12 @@ int ensure_uploaded(mvdb_index *h)
 	if (!ensure_device(h)) return 0;
 	if (h->dev.built_version == h->g.version) return 1;
 	std::string e;
-	if (!h->dev.upload(h->g, e)) {
+	const int p = h->dev.patch(h->g, e);  // inserts / upserts since the last upload: only their rows move
+	if (p < 0 || (p == 0 && !h->dev.upload(h->g, e))) {
 		h->set_error("device upload failed: " + e);
 		return 0;
 	}
+	h->g.clear_dirty();
 	return 1;
 }
 
@@ -1364,6 +1486,13 @@ int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)
 }
 
 int mvdb_check_errors(mvdb_index *h) { return check_device_errors(h); }
+
+void mvdb_upload_counters(const mvdb_index *h, long long *out3)
+{
+	out3[0] = h->dev.full_uploads;
+	out3[1] = h->dev.patches;
+	out3[2] = h->dev.nodes_patched;
+}
 
 void mvdb_debug_inject_abort(mvdb_index *h, int query) { h->inject_abort_q = query; }
 

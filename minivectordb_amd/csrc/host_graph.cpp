@@ -89,6 +89,9 @@ void HostGraph::init(const GraphConfig &c, int capacity)
 	element_count = 0;
 	ef_clamped = false;
 	version++;
+	dirty_all = true;
+	dirty.clear();
+	dirty_flag.clear();
 	level.clear();
 	vec.clear();
 	cnt0.clear();
@@ -127,6 +130,7 @@ int32_t *HostGraph::list_count(int id, int layer)
 
 void HostGraph::create_node(int id, int lvl)  // insert :730-747 / load_index :1201-1205
 {
+	mark_dirty(id);
 	level[id] = (int8_t)lvl;
 	cnt0[id] = 0;
 	std::fill_n(adj0.begin() + (size_t)id * cfg.m0(), cfg.m0(), -1);
@@ -439,6 +443,7 @@ void HostGraph::remove_connection(int src, int dst, int layer)
 		ids[i] = ids[count - 1];  // swap with last active, :664-670
 		ids[count - 1] = -1;
 		*cnt_p = count - 1;
+		mark_dirty(src);
 		return;
 	}
 }
@@ -455,6 +460,7 @@ int HostGraph::add_connection(int src, int dst, int layer, bool defer_victim)
 	if (count < c) {
 		ids[count] = dst;
 		*cnt_p = count + 1;
+		mark_dirty(src);
 		return -1;
 	}
 	int worst = -1;
@@ -476,6 +482,7 @@ int HostGraph::add_connection(int src, int dst, int layer, bool defer_victim)
 	if (worst >= 0 && dst_d < worst_d) {
 		const int victim = ids[worst];
 		ids[worst] = dst;
+		mark_dirty(src);
 		if (victim >= 0 && victim < max_elements && victim != dst && victim != src) {  // :640-642
 			if (defer_victim) return victim;
 			remove_connection(victim, src, layer);
@@ -500,6 +507,7 @@ void HostGraph::overwrite_neighbors(int id, int layer, int picked, BuildScratch 
 	}
 	*cnt_p = w;
 	std::fill(ids + w, ids + c, -1);
+	mark_dirty(id);
 }
 
 // the per-layer connect loop of insert, :812-827
@@ -570,6 +578,7 @@ void HostGraph::update_vector(int id, const int8_t *v)
 {
 	if (id < 0 || id >= max_elements) return;
 	std::memcpy(vec.data() + (size_t)id * cfg.dim, v, (size_t)cfg.dim);
+	mark_dirty(id);
 	version++;
 }
 
@@ -579,6 +588,7 @@ void HostGraph::update_and_reconnect(int id, const int8_t *v)
 	version++;
 	BuildScratch &s = *main_;
 	std::memcpy(vec.data() + (size_t)id * cfg.dim, v, (size_t)cfg.dim);
+	mark_dirty(id);
 	int lvl = level[id];
 	if (lvl >= kMaxLayers) lvl = kMaxLayers - 1;
 	if (entry_point == -1 || !present(entry_point)) return;
@@ -617,6 +627,7 @@ int HostGraph::bulk_begin(const int8_t *packed, int n, int prefix)
 	n = std::min(n, max_elements);
 	if (n <= 0) return 0;
 	version++;
+	dirty_all = true;
 	std::memcpy(vec.data(), packed, (size_t)n * cfg.dim);
 	std::vector<int8_t> lv((size_t)n);
 	size_t upper_total = 0;
@@ -654,6 +665,7 @@ void HostGraph::build_parallel(const int8_t *packed, int n, int threads)
 	if (n <= 0) return;
 	threads = std::max(threads, 1);
 	version++;
+	dirty_all = true;  // worker threads do not track single nodes
 	std::memcpy(vec.data(), packed, (size_t)n * cfg.dim);
 	std::vector<int8_t> lv((size_t)n);
 	size_t upper_total = 0;

@@ -64,6 +64,26 @@ public:
 	std::vector<int64_t> upper_off;  // offset into `upper`, -1 when level < 1
 	std::vector<int32_t> upper;      // per upper node: level x (count, m ids)
 	uint64_t version = 0;            // bumped by every mutation (device mirror staleness)
+	// Nodes whose row or lists changed since `dirty_base` (the version at the last clear_dirty): what the device
+	// mirror has to patch.  dirty_all = everything changed (init, load, bulk builders): patching is off.
+	std::vector<int32_t> dirty;
+	std::vector<uint8_t> dirty_flag;
+	bool dirty_all = true;
+	uint64_t dirty_base = 0;
+	void mark_dirty(int id)
+	{
+		if (dirty_all || id < 0 || id >= max_elements || dirty_flag[id]) return;
+		dirty_flag[id] = 1;
+		dirty.push_back(id);
+	}
+	void clear_dirty()
+	{
+		for (int id : dirty) dirty_flag[id] = 0;
+		dirty.clear();
+		dirty_all = false;
+		dirty_base = version;
+		if ((int)dirty_flag.size() != max_elements) dirty_flag.assign((size_t)std::max(max_elements, 0), 0);
+	}
 
 	void init(const GraphConfig &c, int capacity);  // init_index, hnsw.ts:361-414
 	bool present(int id) const { return id >= 0 && id < max_elements && level[id] >= 0; }
