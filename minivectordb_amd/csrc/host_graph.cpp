@@ -1,7 +1,10 @@
 // host_graph.cpp -- see host_graph.hpp.  Host C++ only (compiled by hipcc as C++).
 #include "host_graph.hpp"
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <new>
 #include <thread>
 
 namespace mvdb {
@@ -81,6 +84,22 @@ BuildScratch::BuildScratch(int max_elements, int max_cap)
 }
 
 // ------------------------------------------------------------------ storage
+static size_t default_alloc_limit()
+{
+	const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+	if (pages <= 0 || psz <= 0) return (size_t)1 << 46;
+	return (size_t)((double)pages * (double)psz * 0.8);
+}
+size_t HostGraph::alloc_limit_bytes = default_alloc_limit();
+
+size_t HostGraph::bytes_for_capacity(int capacity) const
+{
+	if (capacity <= 0) return 0;
+	// level + row + layer-0 count and list + upper offset + visited stamps of the build scratch + expected upper lists
+	const size_t per = 1 + (size_t)cfg.dim + 4 + 4 * (size_t)cfg.m0() + 8 + 4 + 4 * (size_t)(1 + cfg.m);
+	return per * (size_t)capacity;
+}
+
 void HostGraph::init(const GraphConfig &c, int capacity)
 {
 	cfg = c;
@@ -207,9 +226,14 @@ bool HostGraph::load(const uint8_t *buf, size_t size)
 	if (d_entry != -1 && (d_entry < 0 || d_entry >= d_max)) return false;  // :1167-1169
 	if (d_maxlvl < -1 || d_maxlvl >= kMaxLayers) return false;   // :1170
 	if (d_present > 0 && d_entry == -1) return false;            // :1173
+	if (bytes_for_capacity(d_max) > alloc_limit_bytes) return false;  // memory.grow would trap (memory.ts:46-49)
 	if (d_rcap > 0) results_cap = std::min(d_rcap, kMaxEf);      // :1176-1179
 
-	init(cfg, d_max);                                            // :1181
+	try {
+		init(cfg, d_max);                                        // :1181
+	} catch (const std::bad_alloc &) {
+		return false;
+	}
 	entry_point = d_entry;
 	max_level = d_maxlvl;
 	size_t off = kHeaderBytes;

@@ -93,6 +93,11 @@ public:
 	int32_t *list_count(int id, int layer);
 	const int8_t *row(int id) const { return vec.data() + (size_t)id * cfg.dim; }
 
+	// A dump header names the capacity to allocate (init_index(dump_max_elements), hnsw.ts:1181).  The WASM traps when
+	// memory.grow fails (assembly/memory.ts:46-49) and the bridge reports a failed load; here a capacity whose arrays
+	// would not fit `alloc_limit_bytes` (default: 80 % of physical memory) is a failed load too, not an OOM kill.
+	static size_t alloc_limit_bytes;
+	size_t bytes_for_capacity(int capacity) const;
 	// dump V3
 	size_t dump_size() const;                          // hnsw.ts:1048-1073
 	size_t save(uint8_t *out) const;                   // hnsw.ts:1075-1127

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -196,6 +197,17 @@ static void visited_next_stamp(mvo_scratch *s)
 		memset(s->visited, 0, (size_t)s->visited_len * 4);
 	}
 }
+
+static size_t g_alloc_limit = 0;
+size_t mvo_alloc_limit_bytes(void)
+{
+	if (g_alloc_limit == 0) {
+		long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+		g_alloc_limit = (pages > 0 && psz > 0) ? (size_t)((double)pages * (double)psz * 0.8) : ((size_t)1 << 46);
+	}
+	return g_alloc_limit;
+}
+void mvo_set_alloc_limit_bytes(size_t bytes) { g_alloc_limit = bytes; }
 
 /* ------------------------------------------------------------------ */
 /* hnsw.ts:361-414 init_index                                          */
@@ -1165,6 +1177,10 @@ static int load_index(mvo_index *ix, const uint8_t *ptr, size_t size) /* :1129-1
 	if (dump_max_level < -1 || dump_max_level >= ix->MAX_LAYERS) return 0; /* :1170 */
 	if (dump_present > 0 && dump_entry == -1) return 0;                    /* :1173 */
 
+	/* init_index(dump_max_elements) grows the WASM memory; when memory.grow fails the module traps
+	 * (assembly/memory.ts:46-49) and the bridge reports a failed load.  Same outcome here for a capacity
+	 * whose arrays do not fit the allocation limit (default 80 % of physical memory). */
+	if ((size_t)dump_max_elements * ((size_t)ix->DIM + sizeof(int32_t *) + 4 + 64) > mvo_alloc_limit_bytes()) return 0;
 	if (dump_results_cap > 0) { /* :1176-1179 */
 		ix->results_cap = dump_results_cap;
 		if (ix->results_cap > MAX_EF) ix->results_cap = MAX_EF;

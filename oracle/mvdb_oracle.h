@@ -95,6 +95,9 @@ size_t mvo_save(const mvo_index *ix, uint8_t *buf); /* :1075 */
  * WasmBridge.load (:377-468) a failed load leaves a fresh empty index with the
  * handle's own configured capacity. */
 int mvo_load(mvo_index *ix, const uint8_t *buf, size_t size);
+/* capacity a dump may ask for, in bytes of index arrays (a larger one fails the load, as memory.grow would trap) */
+size_t mvo_alloc_limit_bytes(void);
+void mvo_set_alloc_limit_bytes(size_t bytes);
 
 /* ---- host-side compute of MiniVectorDB (src/mini-vector-db.ts) ---- */
 void mvo_normalize_f32(float *v, int dim);                        /* :963-970 */
