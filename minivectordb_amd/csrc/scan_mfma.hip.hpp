@@ -4,20 +4,23 @@
 // i32 accumulation), then L2 = |q|^2 + |v|^2 - 2C (assembly/math.ts:115 gives the same integer)
 // or dot (math.ts:133).  Order of the result: (value asc, id asc) for L2, (dot desc, id asc).
 //
-// Shape: a workgroup = 4 waves = 256 queries; each wave keeps ITS 64 queries as MFMA A-fragments
-// in registers for the whole sweep (4 row tiles x KS k-steps x 16 B per lane) and owns their
-// running top-k lists in LDS, so waves never synchronise on results.  Node rows stream
-// HBM -> registers -> LDS in 32-row tiles (double buffered, padded rows) shared by the 4 waves.
+// Shape: a workgroup = 8 waves = 256 queries, TWO waves per SIMD: each wave keeps ITS 32 queries as
+// MFMA A-fragments in registers for the whole sweep (2 row tiles x KS k-steps x 16 B per lane) and
+// owns their running top-k lists in LDS, so waves never synchronise on results, and while one
+// wave of a SIMD handles candidates (serial, branchy code) its partner keeps the matrix pipe busy.
+// Node rows stream HBM -> registers -> LDS in 64-row staged tiles (double buffered, padded rows)
+// shared by the 8 waves; a B fragment (one ds_read_b128) feeds two MFMAs: 8 waves x 16 reads per
+// 32-row pass = half of the LDS read rate at full MFMA speed.
 // Grid = query tiles x node splits; splits that share `blockIdx % 8` (one XCD, observed
 // round-robin placement: speed only) sweep the SAME node range, so a node tile is fetched from
 // HBM once per XCD and served to the other query tiles from that XCD's L2.
 // Selection: every query row owns an unsorted LDS buffer of kScanCap 64-bit keys (biased value
 // << 32 | id).  An element that passes the row's 32-bit bound (see "Fast rejection") is appended
-// with one LDS atomic; when a buffer is full the wave compacts that row -- 40 lanes rank the
-// keys against each other through readlane, the best k stay, the k-th becomes the row's new
-// bound -- so the expensive step is paid once per ~kScanCap-k candidates, not per candidate.
-// Nothing is ever dropped: an append that finds the buffer full stays pending until the
-// compaction has run.
+// (slot from one LDS atomic per hit element); when a buffer is full the wave compacts that row --
+// 40 lanes rank the keys against each other through readlane, the best k stay, the k-th becomes
+// the row's new bound -- so the expensive step is paid once per ~kScanCap-k candidates, not per
+// candidate.  Nothing is ever dropped: an append that finds the buffer full stays pending until
+// the compaction has run.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,11 +30,15 @@
 namespace mvdb {
 
 constexpr int kScanMaxK = 32;
-constexpr int kScanQB = 256;  // queries per workgroup
-constexpr int kScanTN = 32;   // node rows per MFMA pass (two 16-column tiles)
+constexpr int kScanQB = 256;    // queries per workgroup
+constexpr int kScanWaves = 8;   // waves per workgroup, 32 query rows each
+constexpr int kScanWR = 32;     // query rows per wave
+constexpr int kScanTN = 32;     // node rows per MFMA pass (two 16-column tiles)
 constexpr int kScanStage = 64;  // node rows staged per barrier (two passes)
-constexpr int kScanCap = 40;  // candidate keys buffered per row before the row is compacted to its best k
-constexpr int kScanListStride = kScanCap + 1;  // u64 entries per row (+1: bank spread)
+// candidate keys buffered per row before the row is compacted to its best k: 24 while k <= 16 (the LDS that
+// saves holds a third node-tile buffer), 40 up to kScanMaxK
+constexpr int kScanCapSmall = 24, kScanCapLarge = 40, kScanSmallK = 16;
+constexpr int kScanThreads = kScanWaves * 64;
 
 using v4i = __attribute__((ext_vector_type(4))) int;
 
@@ -41,11 +48,14 @@ struct ScanArgs {
 	const int8_t *q;
 	int nq, k, metric;
 	int qtiles, s2, nsplit;  // nsplit = 8 * s2
-	int nodes_per_split;     // multiple of kScanStage
+	int nodes_per_split;     // multiple of kScanStage (per level, set by the launcher)
+	int node_lo, node_hi;    // node range of this level
+	int slot0, nslots;       // partial-list slot of split 0 of this level; slots per query over all levels
+	int level0, level_ratio; // level plan (scan_levels)
 	unsigned long long *thr_g;     // [nq] smallest k-th key published by any split, ~0 before the launch
 	unsigned long long *dbg;       // MVDB_SCAN_DEBUG builds: 8 counters (see tools/scan_debug.py)
-	unsigned long long *part_key;  // [nq][nsplit][k]
-	int32_t *part_n;               // [nq][nsplit]
+	unsigned long long *part_key;  // [nq][nslots][k]
+	int32_t *part_n;               // [nq][nslots]
 	int32_t *out_ids, *out_val, *out_count;
 };
 
@@ -56,12 +66,26 @@ __host__ __device__ inline int scan_s2_for(int nq)
 	return s2 < 1 ? 1 : (s2 > 64 ? 64 : s2);
 }
 
-template <int KS>
+template <int CAP>
+__host__ __device__ constexpr size_t scan_wave_lds()  // per wave: lists (+1 entry per row: bank spread), bounds, fills, |q|^2
+{
+	return (size_t)kScanWR * (CAP + 1) * 8 + kScanWR * 8 + kScanWR * 4 + kScanWR * 4;
+}
+
+template <int KS, int CAP, int NB>
 __host__ __device__ constexpr size_t scan_lds_bytes()
 {
-	return (size_t)2 * kScanStage * (KS * 64 + 16)                 // node tiles
-	       + (size_t)2 * kScanStage * 4                             // norms of the tiles
-	       + (size_t)4 * (64 * kScanListStride * 8 + 64 * 8 + 64 * 4 + 64 * 4);
+	return (size_t)NB * kScanStage * (KS * 64 + 16)  // node tiles
+	       + (size_t)NB * kScanStage * 4              // norms of the tiles
+	       + (size_t)kScanWaves * scan_wave_lds<CAP>();
+}
+
+// node-tile buffers: three when they fit beside the lists (the first fragments of the next tile
+// are then readable BEFORE the barrier that ends the current one), else two
+template <int KS, int CAP>
+__host__ __device__ constexpr int scan_buffers()
+{
+	return scan_lds_bytes<KS, CAP, 3>() <= 160 * 1024 ? 3 : 2;
 }
 
 // LDS image of a node tile: 16-byte piece c of row r sits at r * (row bytes + 16) + (c ^ flip(r)) * 16.
@@ -77,27 +101,34 @@ __device__ __forceinline__ unsigned long long scan_key(int val, int id)
 }
 
 // Fast rejection.  A candidate needs key < (row's current bound); its necessary condition on the
-// 32-bit value, val <= tv (tv = value part of the bound), is turned into ONE signed compare per
-// accumulator element by folding the column's norm into the MFMA's C operand:
-//   L2:  val = qq + vn - 2c <= tv  <=>  2c - vn >= qq - tv =: u.  With acc = c - (vn >> 1):
-//        2 acc >= 2c - vn, so every candidate has acc >= (u + 1) >> 1 =: g (conservative by the
-//        parity bit of vn at most; the slow path re-checks the exact 64-bit key).
-//   dot: val = -c <= tv  <=>  acc = c >= -tv =: g.
-// Absent rows start from -2^30 and never pass.  While a row has no bound, g = -2^29.
+// 32-bit value, val <= tv (tv = value part of the bound), is turned into a SIGN test of the
+// accumulator by folding both the column's norm and the row's bound into the MFMA's C operand:
+//   L2:  val = qq + vn - 2c <= tv  <=>  2c - vn >= qq - tv =: u.  With b = c - (vn >> 1):
+//        2 b >= 2c - vn, so every candidate has b >= (u + 1) >> 1 =: g (conservative by the
+//        parity bit of vn at most; the exact 64-bit key is formed for the elements that pass and
+//        the compaction orders by it).
+//   dot: val = -c <= tv  <=>  b = c >= -tv =: g.
+// The accumulator starts at -(vn >> 1) - g (dot: -g), so after the k-steps it holds b - g and
+// "some element of this pass may be a candidate" is max(acc) >= 0: one v_max3 per two elements and
+// one ballot per pass.  The g a pass started from travels with its accumulators (bounds may
+// tighten while the pass is in flight), so the exact c is recovered as acc + g (+ vn >> 1).
+// Absent rows start from -2^30 - g and never pass.  While a row has no bound, g = -2^29.
 // The bound of a row is the smaller of its own k-th key and the smallest k-th key any other
 // node split has published for the same query (a.thr_g, 64-bit atomicMin, polled every
 // kScanPoll tiles): k keys <= that bound exist, so nothing above it can be in the final top-k.
 // The exchange only prunes; the merged result is the same whatever the timing.
-// g of a row without a bound: below every real accumulator (|acc| < 2^25), above the -2^30 start of
-// absent rows, and far enough from both for acc - g not to overflow
+// g of a row without a bound: below every real b (|b| < 2^25), above the -2^30 start of absent
+// rows, and far enough from both for the differences not to overflow
 constexpr int kScanNoBound = -(1 << 29);
 constexpr int kScanPoll = 4;  // staged tiles between polls of the shared bounds
 
-template <int KS>
-__global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
+template <int KS, int METRIC, int CAP>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	constexpr int ROWB = KS * 64 + 16;  // padded LDS row
+	constexpr int NB = scan_buffers<KS, CAP>();
+	constexpr int kScanCap = CAP, kScanListStride = CAP + 1;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const DevIndexView &ix = a.ix;
 
@@ -105,40 +136,45 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 	const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
 	const int qtile = j % a.qtiles, s2i = j / a.qtiles;
 	const int split = xcd * a.s2 + s2i;
-	const int n_begin = split * a.nodes_per_split;
+	const int n_begin = a.node_lo + split * a.nodes_per_split;
 	int n_end = n_begin + a.nodes_per_split;
-	if (n_end > ix.max_elements) n_end = ix.max_elements;
+	if (n_end > a.node_hi) n_end = a.node_hi;
 	const int ntiles = n_end > n_begin ? (n_end - n_begin + kScanStage - 1) / kScanStage : 0;  // staged tiles
 
 	unsigned char *btile = lds;
-	int *bnorm = reinterpret_cast<int *>(lds + (size_t)2 * kScanStage * ROWB);
-	unsigned char *wbase = reinterpret_cast<unsigned char *>(bnorm + 2 * kScanStage) +
-	                       (size_t)wave * (64 * kScanListStride * 8 + 64 * 8 + 64 * 4 + 64 * 4);
+	int *bnorm = reinterpret_cast<int *>(lds + (size_t)NB * kScanStage * ROWB);
+	unsigned char *wbase = reinterpret_cast<unsigned char *>(bnorm + NB * kScanStage) + (size_t)wave * scan_wave_lds<CAP>();
 	unsigned long long *list = reinterpret_cast<unsigned long long *>(wbase);
-	unsigned long long *thr_s = list + 64 * kScanListStride;
-	int *cnt = reinterpret_cast<int *>(thr_s + 64);
-	int *qq_s = cnt + 64;
+	unsigned long long *thr_s = list + kScanWR * kScanListStride;
+	int *cnt = reinterpret_cast<int *>(thr_s + kScanWR);
+	int *qq_s = cnt + kScanWR;
 
-	// ---- this wave's 64 queries -> A fragments (row = l & 15, k bytes [64 ks + 16 (l>>4), +16))
-	const int qbase = qtile * kScanQB + wave * 64;
-	v4i qf[4][KS];
+	// ---- this wave's 32 queries -> A fragments (row = l & 15, k bytes [64 ks + 16 (l>>4), +16))
+	const int qbase = qtile * kScanQB + wave * kScanWR;
+	v4i qf[2][KS];
 #pragma unroll
-	for (int rt = 0; rt < 4; rt++) {
+	for (int rt = 0; rt < 2; rt++) {
 		const int qrow = qbase + rt * 16 + (lane & 15);
 		const int8_t *src = a.q + (size_t)(qrow < a.nq ? qrow : 0) * (size_t)ix.dim;
 #pragma unroll
 		for (int ks = 0; ks < KS; ks++) {
+			// unconditional loads from a clamped address, then a select: a branch around each load would
+			// make every one of them a dependent round trip
 			int w[4];
 #pragma unroll
 			for (int t = 0; t < 4; t++) {
 				const int b = ks * 64 + (lane >> 4) * 16 + 4 * t;
-				w[t] = (qrow < a.nq && b < ix.dim) ? *reinterpret_cast<const int *>(src + b) : 0;
+				const bool ok = qrow < a.nq && b < ix.dim;
+				const int v = *reinterpret_cast<const int *>(src + (b < ix.dim ? b : 0));
+				w[t] = ok ? v : 0;
 			}
 			qf[rt][ks] = v4i{w[0], w[1], w[2], w[3]};
 		}
 	}
-	const int my_qrow = qbase + lane;  // the row this lane owns in the selection structures
-	{  // |q|^2 of row `lane`
+	// lanes 0..31 own row `lane` of the selection structures
+	const bool owner = lane < kScanWR;
+	const int my_qrow = qbase + (lane & (kScanWR - 1));
+	if (owner) {  // |q|^2 of row `lane`
 		int s = 0;
 		if (my_qrow < a.nq) {
 			const int8_t *src = a.q + (size_t)my_qrow * (size_t)ix.dim;
@@ -151,44 +187,31 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 		cnt[lane] = 0;
 		thr_s[lane] = ~0ull;
 	}
-	unsigned long long ext = ~0ull;  // smallest bound other splits published for row `lane`
-	// per lane: the 16 rows its accumulators belong to (the same 16 for the whole quarter-wave):
-	// |q|^2, the 32-bit bound of the fast test and the fill of the row's buffer (kept in step
-	// across the quarter, written to cnt[] only around compactions)
-	int qq_r[16], g_r[16], cnt_r[16];
+	unsigned long long ext = ~0ull;  // smallest bound other splits published for row `lane` (owner lanes)
+	// per lane: the 32-bit bound g of the 8 rows its accumulators belong to, j = rt * 4 + reg:
+	// row = rt * 16 + (lane >> 4) * 4 + reg
+	int g_r[8];
 #pragma unroll
-	for (int i = 0; i < 16; i++) {
-		qq_r[i] = qq_s[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
-		g_r[i] = kScanNoBound;
-		cnt_r[i] = 0;
-	}
-	auto cnt_to_lds = [&]() {
-		if ((lane & 15) == 0) {
-#pragma unroll
-			for (int i = 0; i < 16; i++) cnt[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)] = cnt_r[i];
-		}
-	};
-	auto cnt_from_lds = [&]() {
-#pragma unroll
-		for (int i = 0; i < 16; i++) cnt_r[i] = cnt[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
-	};
+	for (int i = 0; i < 8; i++) g_r[i] = kScanNoBound;
+	auto row_of = [&](int jx) -> int { return (jx >> 2) * 16 + (lane >> 4) * 4 + (jx & 3); };
 
 	// thr_s (exact 64-bit bound per row, LDS) -> g_r (32-bit fast test, registers)
 	auto refresh_bounds = [&]() {
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			const unsigned long long t = thr_s[(i >> 2) * 16 + (lane >> 4) * 4 + (i & 3)];
+		for (int i = 0; i < 8; i++) {
+			const int row = row_of(i);
+			const unsigned long long t = thr_s[row];
 			const int tv = (int)((unsigned)(t >> 32) ^ 0x80000000u);
 			int g = kScanNoBound;
-			if (t != ~0ull) g = a.metric == 0 ? ((qq_r[i] - tv + 1) >> 1) : -tv;
+			if (t != ~0ull) g = METRIC == 0 ? ((qq_s[row] - tv + 1) >> 1) : -tv;
 			g_r[i] = g;
 		}
 	};
 	// Compact the rows in `rows` (bit r = row r) to their best min(n, k) keys, sorted ascending.
 	// Lane j holds key j of the row; its rank is the number of smaller keys (keys are unique).
-	auto compact_rows = [&](unsigned long long rows) {
+	auto compact_rows = [&](unsigned rows) {
 		while (rows) {
-			const int R = __builtin_ctzll(rows);
+			const int R = __builtin_ctz(rows);
 			rows &= rows - 1;
 			int n = __builtin_amdgcn_readfirstlane(cnt[R]);
 			if (n > kScanCap) n = kScanCap;
@@ -215,42 +238,44 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 		}
 	};
 
-	// ---- node tile staging: kScanStage rows x KS*64 bytes, KS 16-byte pieces per thread.  The
-	// loads of staged tile T+1 are issued before the two MFMA passes over tile T and stored to
-	// the other LDS buffer after them: two passes (~2 x 1024 matrix-pipe cycles) cover an L2 hit
-	// and most of an HBM miss.  (A register ring of several tiles does not work with hipcc: it
-	// drains vmcnt to zero at the first MFMA of the loop body, i.e. right after the newest load.)
-	constexpr int PIECES = KS * 4 * kScanStage / 256;
-	const int pieces_row = KS * 4;
+	// ---- node tile staging: kScanStage rows x KS*64 bytes, KS/2 16-byte pieces per thread, through
+	// registers.  Tile t+D (D = NB-1) is loaded during tile t-1, written to its LDS buffer piece by
+	// piece among the MFMAs of the first pass of tile t -- after the barrier that ended the last
+	// reads of that buffer, so the (slow: ~13 cycles each, one path per CU) ds_write_b128 of the 8
+	// waves overlap the matrix pipe instead of queueing up in front of the barrier -- and the
+	// registers are reloaded for tile t+D+1 at the end of that pass.
+	constexpr int PIECES = KS * 4 * kScanStage / kScanThreads;
+	constexpr int pieces_row = KS * 4;
 	const int row_pieces_valid = ix.row_stride >> 4;
 	int4 stage[PIECES];
 	int stage_norm = -1;
-	auto stage_load = [&](int tile) {
+	auto stage_load_piece = [&](int i, int tile) {
+#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 16)  // timing experiment: every tile re-reads the first two (cache hits)
+		tile &= 1;
+#endif
 		const int node0 = n_begin + tile * kScanStage;
-#pragma unroll
-		for (int i = 0; i < PIECES; i++) {
-			const int p = tid + 256 * i;
-			const int r = p / pieces_row, c = p % pieces_row;
-			const int node = node0 + r;
-			int4 v = make_int4(0, 0, 0, 0);
-			if (node < n_end && c < row_pieces_valid)
-				v = *reinterpret_cast<const int4 *>(ix.vec + (size_t)node * (size_t)ix.row_stride + c * 16);
-			stage[i] = v;
-		}
-		if (tid < kScanStage) {
-			const int node = node0 + tid;
-			stage_norm = node < n_end ? a.norm2[node] : -1;
+		const int p = tid + kScanThreads * i;
+		const int r = p / pieces_row, c = p % pieces_row;
+		// no branch around the load (hipcc would wait for it at the next MFMA): rows past the end
+		// re-read the last row and are excluded by their norm (-1); pieces past the row are zeroed
+		// when stored
+		const int node = node0 + r < n_end ? node0 + r : n_end - 1;
+		const int cc = c < row_pieces_valid ? c : 0;
+		stage[i] = *reinterpret_cast<const int4 *>(ix.vec + (size_t)node * (size_t)ix.row_stride + cc * 16);
+		if (i == 0) {
+			const int nn = node0 + (tid & (kScanStage - 1));
+			const int nv = a.norm2[nn < n_end ? nn : n_end - 1];
+			stage_norm = nn < n_end ? nv : -1;
 		}
 	};
-	auto stage_store = [&](int bufi) {
+	auto stage_store_piece = [&](int i, int bufi) {
 		unsigned char *dst = btile + (size_t)bufi * kScanStage * ROWB;
-#pragma unroll
-		for (int i = 0; i < PIECES; i++) {
-			const int p = tid + 256 * i;
-			const int r = p / pieces_row, c = p % pieces_row;
-			*reinterpret_cast<int4 *>(dst + r * ROWB + (c ^ scan_row_flip(r)) * 16) = stage[i];
-		}
-		if (tid < kScanStage) bnorm[bufi * kScanStage + tid] = stage_norm;
+		const int p = tid + kScanThreads * i;
+		const int r = p / pieces_row, c = p % pieces_row;
+		int4 v = stage[i];
+		if (c >= row_pieces_valid) v = make_int4(0, 0, 0, 0);
+		*reinterpret_cast<int4 *>(dst + r * ROWB + (c ^ scan_row_flip(r)) * 16) = v;
+		if (i == 0 && tid < kScanStage) bnorm[bufi * kScanStage + tid] = stage_norm;
 	};
 
 #ifdef MVDB_SCAN_DEBUG
@@ -258,53 +283,48 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 	const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
 	// The (rare) elements that pass the fast test are appended to their row's buffer.  C[row][col]:
-	// col = lane & 15 (node), row = (lane >> 4) * 4 + reg (query); vn0/vn1 = norms of this lane's
-	// two columns; anyg[j] != 0 when some lane passed the test for an element in [8j, 8j+8).
-	auto slow_path = [&](const v4i (&acc)[4][2], int node0, int vn0, int vn1, const unsigned long long (&anyg)[4]) {
+	// col = lane & 15 (node), row = (lane >> 4) * 4 + reg (query) of tile (rt, ct); vn0/vn1 = norms of
+	// this lane's two columns; mg[rt * 2 + ct] = the lane's largest element of that tile; gu = the
+	// bounds these accumulators started from.
+	auto slow_path = [&](const v4i (&acc)[2][2], const int (&mg)[4], const int (&gu)[8], int node0, int vn0, int vn1) {
 #ifdef MVDB_SCAN_DEBUG
 		const unsigned long long t_in = __builtin_amdgcn_s_memtime();
 		dbg_c[1]++;
 #endif
 		unsigned pend = 0;
 #pragma unroll
-		for (int gi = 0; gi < 4; gi++) {
-			if (anyg[gi]) {
+		for (int t = 0; t < 4; t++) {
+			if (__ballot(mg[t] >= 0)) {
 #pragma unroll
-				for (int e = gi * 8; e < gi * 8 + 8; e++)
-					pend |= (acc[(e & 15) >> 2][e >> 4][e & 3] >= g_r[e & 15]) ? (1u << e) : 0u;
+				for (int i = 0; i < 4; i++) pend |= (acc[t >> 1][t & 1][i] >= 0) ? (1u << (t * 4 + i)) : 0u;
 			}
 		}
-		if (vn0 < 0) pend &= 0xffff0000u;
-		if (vn1 < 0) pend &= 0x0000ffffu;
 		while (__ballot(pend != 0)) {
 			bool ovf = false;
 #pragma unroll
-			for (int gi = 0; gi < 4; gi++) {
-				if (__ballot((pend >> (gi * 8)) & 0xffu)) {
+			for (int t = 0; t < 4; t++) {
+				if (__ballot((pend >> (t * 4)) & 0xfu)) {
 #pragma unroll
-					for (int e = gi * 8; e < gi * 8 + 8; e++) {
+					for (int i = 0; i < 4; i++) {
+						const int e = t * 4 + i;
 						const bool pe = (pend >> e) & 1u;
-						const unsigned long long m = __ballot(pe);
-						if (m) {
-							// the 16 lanes of a quarter-wave hold 16 columns of the SAME row: slots by prefix count
-							const int i = e & 15, ct = e >> 4;
-							const unsigned qm = (unsigned)(m >> (lane & 48)) & 0xffffu;
-							const int slot = cnt_r[i] + __builtin_popcount(qm & ((1u << (lane & 15)) - 1u));
-							const int nc = cnt_r[i] + __builtin_popcount(qm);
-							if (pe && slot < kScanCap) {
-								const int row = (i >> 2) * 16 + (lane >> 4) * 4 + (i & 3);
-								const int vn = ct ? vn1 : vn0;
-								int av = acc[i >> 2][ct][i & 3];
-								// keep the key arithmetic inside this (rarely taken) branch: without the barrier
-								// hipcc hoists all 32 keys out of the retry loop and pays for them on every entry
-								asm volatile("" : "+v"(av));
-								const int c = a.metric == 0 ? av + (vn >> 1) : av;
-								const int val = a.metric == 0 ? qq_r[i] + vn - 2 * c : -c;
-								list[row * kScanListStride + slot] = scan_key(val, node0 + ct * 16 + (lane & 15));
-								pend &= ~(1u << e);
+						if (__ballot(pe)) {
+							if (pe) {
+								const int rt = t >> 1, ct = t & 1;
+								const int row = rt * 16 + (lane >> 4) * 4 + i;
+								const int slot = atomicAdd(&cnt[row], 1);  // LDS
+								if (slot < kScanCap) {
+									const int vn = ct ? vn1 : vn0;
+									int av = acc[rt][ct][i];
+									// keep the key arithmetic inside this (rarely taken) branch
+									asm volatile("" : "+v"(av));
+									const int c = av + gu[rt * 4 + i] + (METRIC == 0 ? (vn >> 1) : 0);
+									const int val = METRIC == 0 ? qq_s[row] + vn - 2 * c : -c;
+									list[row * kScanListStride + slot] = scan_key(val, node0 + ct * 16 + (lane & 15));
+									pend &= ~(1u << e);
+								}
+								ovf |= slot + 1 >= kScanCap;
 							}
-							ovf |= nc >= kScanCap;
-							cnt_r[i] = nc < kScanCap ? nc : kScanCap;
 						}
 					}
 				}
@@ -313,16 +333,12 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 			dbg_c[2]++;
 #endif
 			if (__ballot(ovf)) {  // a full buffer keeps its element pending: compact, tighten the bounds, retry
-				cnt_to_lds();
-				const unsigned long long full = __ballot(cnt[lane] >= kScanCap);
+				const unsigned full = (unsigned)__ballot(owner && cnt[lane & (kScanWR - 1)] >= kScanCap);
 #ifdef MVDB_SCAN_DEBUG
-				dbg_c[3] += __builtin_popcountll(full);
-#endif
-#ifdef MVDB_SCAN_DEBUG
+				dbg_c[3] += __builtin_popcount(full);
 				const unsigned long long t_c = __builtin_amdgcn_s_memtime();
 #endif
 				compact_rows(full);
-				cnt_from_lds();
 				refresh_bounds();
 #ifdef MVDB_SCAN_DEBUG
 				dbg_c[7] += __builtin_amdgcn_s_memtime() - t_c;
@@ -333,115 +349,172 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 		dbg_c[4] += __builtin_amdgcn_s_memtime() - t_in;
 #endif
 	};
-	auto col_init = [&](int vn) -> int { return vn < 0 ? -(1 << 30) : (a.metric == 0 ? -(vn >> 1) : 0); };
+	auto col_init = [&](int vn) -> int { return vn < 0 ? -(1 << 30) : (METRIC == 0 ? -(vn >> 1) : 0); };
+	auto tile_max = [&](const v4i &v) -> int {
+		const int m01 = v[0] > v[1] ? v[0] : v[1], m23 = v[2] > v[3] ? v[2] : v[3];
+		return m01 > m23 ? m01 : m23;
+	};
 
-	// Software pipeline: the MFMAs of tile t are issued together with the fast test of tile t-1
+	// Software pipeline: the MFMAs of pass t are issued together with the fast test of pass t-1
 	// (independent instruction streams, one matrix-pipe and one VALU), the rare slow path follows.
-	v4i accA[4][2], accB[4][2];
+	// The B fragments of the first two k-steps of a pass (and its two column norms) are read during
+	// the last MFMAs of the pass before it, across the two halves of a staged tile and -- with three
+	// buffers, where the next tile has been complete since the previous barrier -- across tiles.
+	v4i accA[2][2], accB[2][2];
+	int gA[8], gB[8];
 #pragma unroll
-	for (int rt = 0; rt < 4; rt++) accB[rt][0] = accB[rt][1] = v4i{0, 0, 0, 0};
+	for (int rt = 0; rt < 2; rt++) accB[rt][0] = accB[rt][1] = v4i{-1, -1, -1, -1};
+#pragma unroll
+	for (int i = 0; i < 8; i++) gA[i] = gB[i] = kScanNoBound;
 	int pvn0 = -1, pvn1 = -1, pnode0 = 0;
-	bool have_prev = false;
 	unsigned long long ext_next = ~0ull;
-	if (ntiles > 0) {
-		stage_load(0);
-		stage_store(0);
+	constexpr int D = NB - 1;  // tiles between a tile's LDS store and its use
+	for (int t = 0; t < D && t < ntiles; t++) {
+#pragma unroll
+		for (int i = 0; i < PIECES; i++) stage_load_piece(i, t);
+#pragma unroll
+		for (int i = 0; i < PIECES; i++) stage_store_piece(i, t);
 	}
-	// bounds known before the sweep starts (the warm-start launch, or splits that are ahead)
-	if (my_qrow < a.nq) ext = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	thr_s[lane] = ext;
+	if (D < ntiles) {
+#pragma unroll
+		for (int i = 0; i < PIECES; i++) stage_load_piece(i, D);
+	}
+	// bounds known before the sweep starts (the levels before this one, or splits that are ahead)
+	if (owner) {
+		if (my_qrow < a.nq) ext = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		thr_s[lane] = ext;
+	}
 	__syncthreads();
 	refresh_bounds();
 
-	// one MFMA pass over 32 staged rows (half `half` of buffer `cur`) into accN, with the fast test
-	// of the previous pass (accP) riding along
-	auto pass = [&](int tile, int cur, int half, v4i (&accN)[4][2], const v4i (&accP)[4][2]) {
-		const unsigned char *bt = btile + ((size_t)cur * kScanStage + half * kScanTN) * ROWB;
-		const int *bn = bnorm + cur * kScanStage + half * kScanTN;
-		const int vn0 = bn[lane & 15], vn1 = bn[16 + (lane & 15)];
+	const int frag_off = (lane & 15) * ROWB + ((lane >> 4) ^ scan_row_flip(lane & 15)) * 16;
+	v4i pf[2][2];  // fragments of k-steps 0 and 1 of the upcoming pass
+	int nvn0 = -1, nvn1 = -1;  // its column norms
+	auto prefetch = [&](int buf, int half) {
+		const unsigned char *bp0 = btile + ((size_t)buf * kScanStage + half * kScanTN) * ROWB + frag_off;
+		const unsigned char *bp1 = bp0 + 16 * ROWB;
+		pf[0][0] = *reinterpret_cast<const v4i *>(bp0);
+		pf[0][1] = *reinterpret_cast<const v4i *>(bp1);
+		pf[1][0] = *reinterpret_cast<const v4i *>(bp0 + 64);
+		pf[1][1] = *reinterpret_cast<const v4i *>(bp1 + 64);
+		const int *bn = bnorm + buf * kScanStage + half * kScanTN;
+		nvn0 = bn[lane & 15];
+		nvn1 = bn[16 + (lane & 15)];
+	};
+	if (ntiles > 0) prefetch(0, 0);
+
+	// one MFMA pass over 32 staged rows (half `half` of buffer `cur`) into accN (started from the
+	// bounds gN), with the fast test of the previous pass (accP, started from gP) riding along;
+	// (nbuf, nhalf): the pass whose first fragments are fetched during this one, nbuf < 0: none
+	// st: the staged registers (tile + D) go to buffer `fill` during this pass; ld: they are reloaded (tile + D + 1)
+	auto pass = [&](int tile, int cur, int half, int nbuf, int nhalf, bool st, bool ld, int fill, v4i (&accN)[2][2],
+	                int (&gN)[8], const v4i (&accP)[2][2], const int (&gP)[8]) {
+		const unsigned char *bp0 = btile + ((size_t)cur * kScanStage + half * kScanTN) * ROWB + frag_off;
+		const unsigned char *bp1 = bp0 + 16 * ROWB;
+		const int vn0 = nvn0, vn1 = nvn1;
 		const int c0 = col_init(vn0), c1 = col_init(vn1);
 #pragma unroll
-		for (int rt = 0; rt < 4; rt++) {
-			accN[rt][0] = v4i{c0, c0, c0, c0};
-			accN[rt][1] = v4i{c1, c1, c1, c1};
+		for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int g = g_r[rt * 4 + i];
+				gN[rt * 4 + i] = g;
+				accN[rt][0][i] = c0 - g;
+				accN[rt][1][i] = c1 - g;
+			}
 		}
-		// fast test of the previous pass, kept on the VALU: mg[j] = max over the elements of group j
-		// of (acc - g); a candidate exists iff some lane ends with mg >= 0 (no SGPR traffic between MFMAs)
-		int mg[4] = {-1, -1, -1, -1};
-		const unsigned char *bp0 = bt + (lane & 15) * ROWB + ((lane >> 4) ^ scan_row_flip(lane & 15)) * 16;
-		const unsigned char *bp1 = bp0 + 16 * ROWB;
+		// fast test of the previous pass: the lane's largest element per 16x16 tile (accB starts at -1)
+		int mg[4];
+#pragma unroll
+		for (int t = 0; t < 4; t++) mg[t] = tile_max(accP[t >> 1][t & 1]);
+		const int m01 = mg[0] > mg[1] ? mg[0] : mg[1], m23 = mg[2] > mg[3] ? mg[2] : mg[3];
+		const int mall = m01 > m23 ? m01 : m23;
 		// fragments of k-steps ks+1 and ks+2 are in flight while the MFMAs of ks run
 		v4i bf[KS + 2][2];
-		bf[0][0] = *reinterpret_cast<const v4i *>(bp0);
-		bf[0][1] = *reinterpret_cast<const v4i *>(bp1);
-		bf[1][0] = *reinterpret_cast<const v4i *>(bp0 + 64);
-		bf[1][1] = *reinterpret_cast<const v4i *>(bp1 + 64);
-		constexpr int PER = 32 / (KS * 4);
+		bf[0][0] = pf[0][0];
+		bf[0][1] = pf[0][1];
+		bf[1][0] = pf[1][0];
+		bf[1][1] = pf[1][1];
 #pragma unroll
 		for (int ks = 0; ks < KS; ks++) {
+#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 4)  // timing experiments only: no fragment reads from LDS
+			if (ks + 2 < KS) {
+				bf[ks + 2][0] = bf[ks][1];
+				bf[ks + 2][1] = bf[ks][0];
+				asm volatile("" : "+v"(bf[ks + 2][0]), "+v"(bf[ks + 2][1]));
+			}
+#else
 			if (ks + 2 < KS) {
 				bf[ks + 2][0] = *reinterpret_cast<const v4i *>(bp0 + (ks + 2) * 64);
 				bf[ks + 2][1] = *reinterpret_cast<const v4i *>(bp1 + (ks + 2) * 64);
 			}
+			if (ks == KS - 2 && nbuf >= 0) prefetch(nbuf, nhalf);
+#endif
+			// (stores first, then every reload: a reload issued between two stores would make the
+			// next store's vmcnt wait cover it)
+#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 8)  // ... no staging
+			if (false) {
+#else
+			if (st && (ks & 1) == 0 && (ks >> 1) < PIECES) stage_store_piece(ks >> 1, fill);
+			if (ld && ks == KS - 1) {
+#endif
 #pragma unroll
-			for (int rt = 0; rt < 4; rt++) {
+				for (int i = 0; i < PIECES; i++) stage_load_piece(i, tile + D + 1);
+			}
+#pragma unroll
+			for (int rt = 0; rt < 2; rt++) {
 				accN[rt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], bf[ks][0], accN[rt][0], 0, 0, 0);
 				accN[rt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], bf[ks][1], accN[rt][1], 0, 0, 0);
-#pragma unroll
-				for (int u = 0; u < PER; u++) {
-					const int e = (ks * 4 + rt) * PER + u;
-					const int d = accP[(e & 15) >> 2][e >> 4][e & 3] - g_r[e & 15];
-					mg[e >> 3] = d > mg[e >> 3] ? d : mg[e >> 3];
-				}
 			}
-			__builtin_amdgcn_sched_barrier(0);
 		}
-#pragma unroll
-		for (int e = PER * KS * 4; e < 32; e++) {
-			const int d = accP[(e & 15) >> 2][e >> 4][e & 3] - g_r[e & 15];
-			mg[e >> 3] = d > mg[e >> 3] ? d : mg[e >> 3];
-		}
-		unsigned long long anyg[4];
-#pragma unroll
-		for (int j = 0; j < 4; j++) anyg[j] = __ballot(mg[j] >= 0);
-		if (have_prev && (anyg[0] | anyg[1] | anyg[2] | anyg[3])) slow_path(accP, pnode0, pvn0, pvn1, anyg);
+#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 2)  // timing experiments only (wrong results; bit flags): no fast test
+		asm volatile("" ::"v"(accP[0][0][0]), "v"(accP[0][1][0]), "v"(accP[1][0][0]), "v"(accP[1][1][0]));
+#elif defined(MVDB_SCAN_ABLATE)  // fast test kept, candidates never handled
+		if (__ballot(mall >= 0)) asm volatile("s_nop 0");
+#else
+		if (__ballot(mall >= 0)) slow_path(accP, mg, gP, pnode0, pvn0, pvn1);
+#endif
 		pvn0 = vn0;
 		pvn1 = vn1;
 		pnode0 = n_begin + tile * kScanStage + half * kScanTN;
-		have_prev = true;
 #ifdef MVDB_SCAN_DEBUG
 		dbg_c[0]++;
 #endif
 	};
+	int cur = 0;
 	for (int tile = 0; tile < ntiles; tile++) {
-		const int cur = tile & 1;
-		if (tile + 1 < ntiles) stage_load(tile + 1);  // in flight under both passes
-		if ((tile % kScanPoll) == 0 && my_qrow < a.nq)
+		const int nxt = cur + 1 == NB ? 0 : cur + 1;
+		const int fill = cur == 0 ? NB - 1 : cur - 1;  // (cur + D) % NB: the buffer of tile + D
+		const bool more = tile + 1 < ntiles;
+		if ((tile % kScanPoll) == 0 && owner && my_qrow < a.nq)
 			ext_next = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		pass(tile, cur, 0, accA, accB);
-		pass(tile, cur, 1, accB, accA);
-		if ((tile % kScanPoll) == 1 && ext_next < ext) {  // a tighter bound from another split
-			ext = ext_next;
-			if (ext < thr_s[lane]) thr_s[lane] = ext;
+		pass(tile, cur, 0, cur, 1, tile + D < ntiles, tile + D + 1 < ntiles, fill, accA, gA, accB, gB);
+		pass(tile, cur, 1, (NB >= 3 && more) ? nxt : -1, 0, false, false, 0, accB, gB, accA, gA);
+		if ((tile % kScanPoll) == 1 && __ballot(owner && ext_next < ext)) {  // a tighter bound from another split
+			if (owner && ext_next < ext) {
+				ext = ext_next;
+				if (ext < thr_s[lane]) thr_s[lane] = ext;
+			}
 			refresh_bounds();
 		}
 #ifdef MVDB_SCAN_DEBUG
 		const unsigned long long t_b = __builtin_amdgcn_s_memtime();
 #endif
-		if (tile + 1 < ntiles) stage_store(cur ^ 1);
 		__syncthreads();
+		if (NB < 3 && more) prefetch(nxt, 0);
 #ifdef MVDB_SCAN_DEBUG
 		dbg_c[5] += __builtin_amdgcn_s_memtime() - t_b;
 #endif
+		cur = nxt;
 	}
-	if (have_prev) {  // the last pass always ran into accB
-		unsigned long long anyg[4] = {0, 0, 0, 0};
+	if (ntiles > 0) {  // the last pass always ran into accB
+		int mg[4];
 #pragma unroll
-		for (int e = 0; e < 32; e++) anyg[e >> 3] |= __ballot(accB[(e & 15) >> 2][e >> 4][e & 3] >= g_r[e & 15]);
-		if (anyg[0] | anyg[1] | anyg[2] | anyg[3]) slow_path(accB, pnode0, pvn0, pvn1, anyg);
+		for (int t = 0; t < 4; t++) mg[t] = tile_max(accB[t >> 1][t & 1]);
+		const int m01 = mg[0] > mg[1] ? mg[0] : mg[1], m23 = mg[2] > mg[3] ? mg[2] : mg[3];
+		if (__ballot((m01 > m23 ? m01 : m23) >= 0)) slow_path(accB, mg, gB, pnode0, pvn0, pvn1);
 	}
-	cnt_to_lds();
-	compact_rows(__ballot(cnt[lane] > 0));  // every row: best min(n, k), sorted
+	compact_rows((unsigned)__ballot(owner && cnt[lane & (kScanWR - 1)] > 0));  // every row: best min(n, k), sorted
 #ifdef MVDB_SCAN_DEBUG
 	dbg_c[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
 	if (lane == 0 && a.dbg)
@@ -449,111 +522,122 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a)
 #endif
 
 	// ---- per-(query, split) partial lists, sorted ascending
-	if (my_qrow < a.nq) {
+	if (owner && my_qrow < a.nq) {
 		const unsigned long long *L = list + lane * kScanListStride;
 		const int mylen = cnt[lane];
-		const size_t o = ((size_t)my_qrow * a.nsplit + split) * (size_t)a.k;
+		const size_t o = ((size_t)my_qrow * a.nslots + a.slot0 + split) * (size_t)a.k;
 		for (int i = 0; i < mylen; i++) a.part_key[o + i] = L[i];
-		a.part_n[(size_t)my_qrow * a.nsplit + split] = mylen;
+		a.part_n[(size_t)my_qrow * a.nslots + a.slot0 + split] = mylen;
 	}
 }
 
-// merge the nsplit sorted partial lists of each query: one thread per query
-__global__ void scan_merge_kernel(ScanArgs a)
+// k-way merge of the sorted partial lists of one query: one wave per query, lane l owns slots
+// l, l + 64, ...; k rounds of "smallest key above the last one taken" (keys are unique: ids differ).
+// FINAL: write ids / values / count.  Otherwise: thr_g[q] = the k-th smallest key seen so far
+// ("k keys <= this bound exist"; the later levels visit other nodes, so no later key equals it).
+template <bool FINAL>
+__global__ __launch_bounds__(256) void scan_merge_kernel(ScanArgs a, int slots_used)
 {
-	const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (qi >= a.nq) return;
-	const unsigned long long *pk = a.part_key + (size_t)qi * a.nsplit * a.k;
-	const int32_t *pn = a.part_n + (size_t)qi * a.nsplit;
-	unsigned long long last = 0;
-	bool have_last = false;
-	int out = 0;
-	for (; out < a.k; out++) {
-		// smallest key strictly greater than `last` (keys are unique: ids differ)
-		unsigned long long best = ~0ull;
-		bool found = false;
-		for (int s = 0; s < a.nsplit; s++) {
-			const int n = pn[s];
-			// lists are sorted: first entry > last by binary search would do; k is small, scan
-			for (int i = 0; i < n; i++) {
-				const unsigned long long key = pk[(size_t)s * a.k + i];
-				if (have_last && key <= last) continue;
-				if (!found || key < best) {
-					best = key;
-					found = true;
-				}
-				break;
-			}
-		}
-		if (!found) break;
-		last = best;
-		have_last = true;
-		const int val = (int)((unsigned)(best >> 32) ^ 0x80000000u);
-		a.out_ids[(size_t)qi * a.k + out] = (int)(unsigned)best;
-		a.out_val[(size_t)qi * a.k + out] = a.metric == 0 ? val : -val;
-	}
-	a.out_count[qi] = out;
-	for (int i = out; i < a.k; i++) {  // deterministic tail
-		a.out_ids[(size_t)qi * a.k + i] = -1;
-		a.out_val[(size_t)qi * a.k + i] = 0;
-	}
-}
-
-// Warm start (see launch_scan): after a sweep over a prefix of the nodes, thr_g[q] = (k-th smallest
-// key of the prefix) + 1 -- "k keys below this bound exist".  +1 because the full sweep visits the
-// prefix again and must still accept that very key (keys are unique: value << 32 | id).
-__global__ void scan_bound_kernel(ScanArgs a)
-{
-	const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (qi >= a.nq) return;
-	const unsigned long long *pk = a.part_key + (size_t)qi * a.nsplit * a.k;
-	const int32_t *pn = a.part_n + (size_t)qi * a.nsplit;
+	const unsigned long long *pk = a.part_key + (size_t)qi * a.nslots * a.k;
+	const int32_t *pn = a.part_n + (size_t)qi * a.nslots;
 	unsigned long long last = 0;
 	bool have_last = false;
 	int out = 0;
 	for (; out < a.k; out++) {
 		unsigned long long best = ~0ull;
-		bool found = false;
-		for (int s = 0; s < a.nsplit; s++) {
+		for (int s = lane; s < slots_used; s += 64) {
 			const int n = pn[s];
 			for (int i = 0; i < n; i++) {
 				const unsigned long long key = pk[(size_t)s * a.k + i];
 				if (have_last && key <= last) continue;
-				if (!found || key < best) {
-					best = key;
-					found = true;
-				}
+				best = key < best ? key : best;
 				break;
 			}
 		}
-		if (!found) break;
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) {
+			const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, d, 64);
+			const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), d, 64);
+			const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+			best = o < best ? o : best;
+		}
+		if (best == ~0ull) break;
 		last = best;
 		have_last = true;
+		if (FINAL && lane == 0) {
+			const int val = (int)((unsigned)(best >> 32) ^ 0x80000000u);
+			a.out_ids[(size_t)qi * a.k + out] = (int)(unsigned)best;
+			a.out_val[(size_t)qi * a.k + out] = a.metric == 0 ? val : -val;
+		}
 	}
-	a.thr_g[qi] = out == a.k ? last + 1 : ~0ull;
+	if (FINAL) {
+		if (lane == 0) a.out_count[qi] = out;
+		for (int i = out + lane; i < a.k; i += 64) {  // deterministic tail
+			a.out_ids[(size_t)qi * a.k + i] = -1;
+			a.out_val[(size_t)qi * a.k + i] = 0;
+		}
+	} else if (lane == 0) {
+		a.thr_g[qi] = out == a.k ? last : ~0ull;
+	}
 }
 
-constexpr int kScanWarmNodes = 8192;  // prefix swept first to seed the bounds
+// Levels.  With S node splits sweeping at once, a split only learns from its own 1/S of the
+// nodes (and the k-th keys the others publish, which are no tighter than its own), so a sweep
+// costs ~S * k * ln(N / n0) appends per query instead of k * ln(N / n0).  The node range is
+// therefore swept in levels [0, n0), [n0, r n0), [r n0, r^2 n0), ...: after each level the k-th
+// key over ALL splits and levels so far becomes every row's bound, and the next level -- r - 1
+// times as many nodes as everything before it -- produces ~k (r - 1) appends per query in
+// total, whatever S is.  Every level writes its own partial lists (slot = level * nsplit +
+// split); the final merge takes all of them.  No node is visited twice.
+constexpr int kScanLevel0 = 4096;   // nodes of the first level (no bound yet)
+constexpr int kScanLevelRatio = 4;  // each later level ends at ratio x its start
+constexpr int kScanMaxLevels = 16;
 
-template <int KS>
-inline bool launch_scan_t(const ScanArgs &a, hipStream_t s)
+// ends[i] = end of level i (multiples of kScanStage, last = N); returns the number of levels
+__host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 = kScanLevel0, int ratio = kScanLevelRatio)
 {
-	const size_t lds = scan_lds_bytes<KS>();
-	if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KS>),
-	                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-		return false;
-	// Most candidates of a sweep turn up in its first few thousand nodes, when the bounds are
-	// still loose and every split learns them separately.  Sweeping a short prefix first and
-	// starting the full sweep from its k-th keys removes ~90 % of the slow-path entries.
-	if (a.ix.max_elements >= 8 * kScanWarmNodes) {
-		ScanArgs w = a;
-		w.ix.max_elements = kScanWarmNodes;
-		w.nodes_per_split = (((kScanWarmNodes + w.nsplit - 1) / w.nsplit) + kScanStage - 1) / kScanStage * kScanStage;
-		hipLaunchKernelGGL((scan_kernel<KS>), dim3(w.qtiles * w.nsplit), dim3(256), lds, s, w);
-		hipLaunchKernelGGL(scan_bound_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, s, w);
+	int n = 0;
+	long long e = level0;
+	while (e < N && n < kScanMaxLevels - 1) {
+		ends[n++] = (int)e;
+		e *= ratio;
 	}
-	hipLaunchKernelGGL((scan_kernel<KS>), dim3(a.qtiles * a.nsplit), dim3(256), lds, s, a);
-	hipLaunchKernelGGL(scan_merge_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, s, a);
+	ends[n++] = N;
+	return n;
+}
+
+template <int KS, int METRIC, int CAP>
+inline bool launch_scan_t(const ScanArgs &a0, hipStream_t s)
+{
+	const size_t lds = scan_lds_bytes<KS, CAP, scan_buffers<KS, CAP>()>();
+	static bool attr_set[16] = {};  // per device, once
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+	if (!attr_set[dev]) {
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KS, METRIC, CAP>),
+		                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+			return false;
+		attr_set[dev] = true;
+	}
+	int ends[kScanMaxLevels];
+	const int levels = scan_levels(a0.ix.max_elements, ends, a0.level0, a0.level_ratio);
+	if (levels * a0.nsplit > a0.nslots) return false;
+	ScanArgs a = a0;
+	int lo = 0;
+	for (int l = 0; l < levels; l++) {
+		a.node_lo = lo;
+		a.node_hi = ends[l];
+		a.slot0 = l * a.nsplit;
+		a.nodes_per_split = (((a.node_hi - a.node_lo + a.nsplit - 1) / a.nsplit) + kScanStage - 1) / kScanStage * kScanStage;
+		hipLaunchKernelGGL((scan_kernel<KS, METRIC, CAP>), dim3(a.qtiles * a.nsplit), dim3(kScanThreads), lds, s, a);
+		if (l + 1 < levels)
+			hipLaunchKernelGGL(scan_merge_kernel<false>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a, (l + 1) * a.nsplit);
+		lo = ends[l];
+	}
+	hipLaunchKernelGGL(scan_merge_kernel<true>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a, levels * a.nsplit);
 	return hipGetLastError() == hipSuccess;
 }
 
@@ -561,10 +645,27 @@ inline bool launch_scan_t(const ScanArgs &a, hipStream_t s)
 inline bool launch_scan(const ScanArgs &a, hipStream_t s)
 {
 	const int ks = (a.ix.row_stride + 63) / 64;
-	if (ks <= 2) return launch_scan_t<2>(a, s);
-	if (ks <= 4) return launch_scan_t<4>(a, s);
-	if (ks <= 6) return launch_scan_t<6>(a, s);
-	if (ks <= 8) return launch_scan_t<8>(a, s);
+	const int sel = (ks <= 2 ? 0 : ks <= 4 ? 1 : ks <= 6 ? 2 : ks <= 8 ? 3 : 4) * 4 + (a.metric == 0 ? 0 : 2) +
+	                (a.k <= kScanSmallK ? 0 : 1);
+	switch (sel) {
+	case 0: return launch_scan_t<2, 0, kScanCapSmall>(a, s);
+	case 1: return launch_scan_t<2, 0, kScanCapLarge>(a, s);
+	case 2: return launch_scan_t<2, 1, kScanCapSmall>(a, s);
+	case 3: return launch_scan_t<2, 1, kScanCapLarge>(a, s);
+	case 4: return launch_scan_t<4, 0, kScanCapSmall>(a, s);
+	case 5: return launch_scan_t<4, 0, kScanCapLarge>(a, s);
+	case 6: return launch_scan_t<4, 1, kScanCapSmall>(a, s);
+	case 7: return launch_scan_t<4, 1, kScanCapLarge>(a, s);
+	case 8: return launch_scan_t<6, 0, kScanCapSmall>(a, s);
+	case 9: return launch_scan_t<6, 0, kScanCapLarge>(a, s);
+	case 10: return launch_scan_t<6, 1, kScanCapSmall>(a, s);
+	case 11: return launch_scan_t<6, 1, kScanCapLarge>(a, s);
+	case 12: return launch_scan_t<8, 0, kScanCapSmall>(a, s);
+	case 13: return launch_scan_t<8, 0, kScanCapLarge>(a, s);
+	case 14: return launch_scan_t<8, 1, kScanCapSmall>(a, s);
+	case 15: return launch_scan_t<8, 1, kScanCapLarge>(a, s);
+	default: break;
+	}
 	return false;
 }
 

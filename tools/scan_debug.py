@@ -34,3 +34,5 @@ print(f"wave-tiles {tiles}  slow-path entries {entries} ({entries / max(tiles, 1
 print(f"row compactions {rows_flushed} ({rows_flushed / max(tiles, 1):.3f}/tile)")
 print(f"wave cycles: total {total_cyc:.3g}  slow path {100 * slow_cyc / total_cyc:.1f}%  "
       f"stage store + barrier {100 * store_barrier_cyc / total_cyc:.1f}%  per tile {total_cyc / max(tiles, 1):.0f}")
+if os.environ.get("MVDB_SCAN_ABLATE_STAMPS"):
+    print(f"end of tile per wave-tile: wait for loads {iters / tiles:.0f}  LDS stores {rows_flushed / tiles:.0f}  barrier {compact_cyc / tiles:.0f} cycles")
