@@ -555,6 +555,32 @@ def run_scan(args, torch, dist, dev, rank, world):
                    sample=f"first {ns} queries, exhaustive int8 scan of the same {n} rows (C oracle)",
                    gpu_matches_oracle_on_sample=same)
         ix.close()
+    second = None
+    if rank == 0 and world == 1 and args.second_dataset != "none":
+        # the same scan + the HNSW comparison on a set with neighbourhood structure (the i.i.d. set has none at 1 M)
+        b.close()
+        b = HipBridge(device=dev.index)
+        b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], efSearch=p["baseEfSearch"], capacity=n, seed=42,
+                    resultsCap=4096))
+        base2, c8 = normalise_quantise(b, make_rows(n, dim, 12345 + 777, True))
+        run_with_heartbeat(lambda: b.buildGpu(c8), "GPU build (clustered)")
+        cq = make_queries(1, nq, dim, 999, base2, True)[0]
+        cq8 = normalise_quantise(b, cq)[1]
+        qd.copy_(torch.from_numpy(cq8))
+        L, h = b._L, b.handle
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        el2 = time.perf_counter() - t1
+        b.setEfSearch(p["baseEfSearch"])
+        hi2, _, _ = b.searchManyArrays(cq8[:1000], k * p["rerankMultiplier"])
+        second = dict(data=f"{CLUSTERS} Gaussian clusters, sigma {CLUSTER_SIGMA}", ms_per_step=round(el2 / args.steps * 1e3, 4),
+                      value=round(nq / (el2 / args.steps), 2), unit="queries/s",
+                      hnsw_recall_vs_exact_int8=round(recall_of(hi2, ids[:1000].cpu().numpy(), k), 4))
     out = None
     if rank == 0:
         out = dict(metric="exact int8 scan QPS (top-10, int8 MFMA)", value=round(world * nq / (el / args.steps), 2),
@@ -570,7 +596,7 @@ def run_scan(args, torch, dist, dev, rank, world):
                    hnsw_recall_vs_exact_int8=dict(value=round(hn_recall, 4), queries=1000,
                                                   what=f"traversal candidates (ef={k * p['rerankMultiplier']}) top-{k} by "
                                                        f"int8 distance vs the exact scan's top-{k}"),
-                   cpu_baseline=cpu)
+                   second_dataset=second, cpu_baseline=cpu)
     b.close()
     return out
 

@@ -1383,8 +1383,8 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	HIP_OK(h, hipMemsetAsync(a.thr_g, 0xff, (size_t)nq * 8, s));
 	a.dbg = nullptr;
 #ifdef MVDB_SCAN_DEBUG
-	a.dbg = static_cast<unsigned long long *>(h->prof_buf.need(64));
-	HIP_OK(h, hipMemsetAsync(a.dbg, 0, 64, s));
+	a.dbg = static_cast<unsigned long long *>(h->prof_buf.need(128));
+	HIP_OK(h, hipMemsetAsync(a.dbg, 0, 128, s));
 #endif
 	a.out_ids = d_out_ids;
 	a.out_val = d_out_val;
@@ -1471,7 +1471,7 @@ int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, i
 int mvdb_debug_scan_counters(mvdb_index *h, unsigned long long *out)
 {
 	if (!h->prof_buf.p) return 0;
-	return hipMemcpy(out, h->prof_buf.p, 64, hipMemcpyDeviceToHost) == hipSuccess;
+	return hipMemcpy(out, h->prof_buf.p, 128, hipMemcpyDeviceToHost) == hipSuccess;
 }
 #endif
 #ifdef MVDB_TRAVERSE_PROFILE

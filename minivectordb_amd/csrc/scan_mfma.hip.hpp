@@ -120,7 +120,27 @@ __device__ __forceinline__ unsigned long long scan_key(int val, int id)
 // g of a row without a bound: below every real b (|b| < 2^25), above the -2^30 start of absent
 // rows, and far enough from both for the differences not to overflow
 constexpr int kScanNoBound = -(1 << 29);
-constexpr int kScanPoll = 4;  // staged tiles between polls of the shared bounds
+
+// Staging path.  1 (default): LDS-DMA (global_load_lds_dwordx4): node tiles go HBM/L2 -> LDS without
+// passing through registers, two tiles ahead with three buffers, counted vmcnt + raw s_barrier.
+// 0: through registers (global_load_dwordx4 + ds_write_b128), kept for A/B measurements.
+#ifndef MVDB_SCAN_DMA
+#define MVDB_SCAN_DMA 1
+#endif
+#if MVDB_SCAN_DMA
+constexpr int kScanPoll = 16;  // staged tiles between polls of the shared bounds (an ordinary load drains the DMA queue)
+#else
+constexpr int kScanPoll = 4;
+#endif
+// sources of the LDS-DMA lanes that have nothing to fetch: pad slots, pieces past the row, rows past the end
+static __device__ __align__(16) int g_scan_zero[4] = {0, 0, 0, 0};
+static __device__ int g_scan_neg1 = -1;
+
+template <int N>
+__device__ __forceinline__ void scan_wait_vm()
+{
+	asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <int KS, int METRIC, int CAP>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
@@ -278,8 +298,64 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 		if (i == 0 && tid < kScanStage) bnorm[bufi * kScanStage + tid] = stage_norm;
 	};
 
+#if MVDB_SCAN_DMA
+	// ---- LDS-DMA staging.  A wave-instruction writes 64 consecutive 16-byte slots of LDS (M0 base +
+	// lane * 16) from per-lane global addresses, so the padded, pair-swapped tile image is filled
+	// slot by slot: slot s = row s / (KS*4+1), position s % (KS*4+1); position p holds piece
+	// p ^ flip(row), the last position of a row is the pad.  64 rows x (KS*4+1) slots = KS*4+1
+	// instructions per tile; one more (4 bytes per lane) brings the 64 norms.  Lanes with nothing
+	// to fetch read a zero block (rows past the end: norm -1).
+	// Issuing them costs the issuing wave ~150 cycles each (measured, whichever way a tile is staged
+	// the LDS fill is paid in issue time), and a wave issues in order, so the two waves of a SIMD
+	// must not do it at the same time: waves 0-3 (one per SIMD) fetch the even tiles, waves 4-7 the
+	// odd ones, right after the barrier, and the partner has the matrix pipe to itself meanwhile
+	// (measured against every wave issuing its share of every tile, staggered by half a tile: 8 %
+	// faster).  Full tiles of full rows take the short form: uniform base + per-lane offset.
+	constexpr int SLOTS_ROW = KS * 4 + 1;
+	constexpr int DMA_PER_TILE = kScanStage * SLOTS_ROW / 64;
+	constexpr int DMA_MAX = (DMA_PER_TILE + 3) / 4;
+	const int dma_grp = wave >> 2, dma_w = wave & 3;
+	int dma_off[DMA_MAX], dma_row[DMA_MAX];
+	const bool full_rows = row_pieces_valid >= KS * 4;
+#pragma unroll
+	for (int i = 0; i < DMA_MAX; i++) {
+		const int slot = (dma_w + 4 * i) * 64 + lane;
+		const int r = slot / SLOTS_ROW, cpos = slot - r * SLOTS_ROW;
+		const int c = cpos ^ scan_row_flip(r);
+		dma_row[i] = r;
+		// pad slots are never read: with full rows they fetch piece 0 of their row, so that no lane needs the zero block
+		dma_off[i] = (cpos < KS * 4 && c < row_pieces_valid) ? r * ix.row_stride + c * 16 : (full_rows ? r * ix.row_stride : -1);
+	}
+	using lds_ptr_t = __attribute__((address_space(3))) void *;
+	using glb_ptr_t = __attribute__((address_space(1))) void *;
+	auto dma_issue = [&](int tile, int bufi) {
+		const int node0 = n_begin + tile * kScanStage;
+		const int rows_left = n_end - node0;
+		const int8_t *base = ix.vec + (size_t)node0 * (size_t)ix.row_stride;
+		unsigned char *dst = btile + (size_t)bufi * kScanStage * ROWB;
+#pragma unroll
+		for (int i = 0; i < DMA_MAX; i++) {
+			const int j = dma_w + 4 * i;
+			if (j < DMA_PER_TILE) {  // wave-uniform
+				if (full_rows && rows_left >= kScanStage) {  // wave-uniform: uniform base + 32-bit lane offset
+					__builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (unsigned)dma_off[i]), (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+				} else {
+					const bool ok = dma_off[i] >= 0 && dma_row[i] < rows_left;
+					const void *src = ok ? static_cast<const void *>(base + dma_off[i]) : static_cast<const void *>(g_scan_zero);
+					__builtin_amdgcn_global_load_lds((glb_ptr_t)(src), (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+				}
+			}
+		}
+		if (dma_w == 3) {
+			const int nn = node0 + lane;
+			const void *src = nn < n_end ? static_cast<const void *>(a.norm2 + nn) : static_cast<const void *>(&g_scan_neg1);
+			__builtin_amdgcn_global_load_lds((glb_ptr_t)(src), (lds_ptr_t)(bnorm + bufi * kScanStage), 4, 0, 0);
+		}
+	};
+#endif
+
 #ifdef MVDB_SCAN_DEBUG
-	unsigned long long dbg_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long dbg_c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
 	// The (rare) elements that pass the fast test are appended to their row's buffer.  C[row][col]:
@@ -369,6 +445,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 	int pvn0 = -1, pvn1 = -1, pnode0 = 0;
 	unsigned long long ext_next = ~0ull;
 	constexpr int D = NB - 1;  // tiles between a tile's LDS store and its use
+#if MVDB_SCAN_DMA
+	for (int t = 0; t < NB && t < ntiles; t++)
+		if ((t & 1) == dma_grp) dma_issue(t, t);
+	scan_wait_vm<0>();
+#else
 	for (int t = 0; t < D && t < ntiles; t++) {
 #pragma unroll
 		for (int i = 0; i < PIECES; i++) stage_load_piece(i, t);
@@ -379,6 +460,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 #pragma unroll
 		for (int i = 0; i < PIECES; i++) stage_load_piece(i, D);
 	}
+#endif
 	// bounds known before the sweep starts (the levels before this one, or splits that are ahead)
 	if (owner) {
 		if (my_qrow < a.nq) ext = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -409,6 +491,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 	// st: the staged registers (tile + D) go to buffer `fill` during this pass; ld: they are reloaded (tile + D + 1)
 	auto pass = [&](int tile, int cur, int half, int nbuf, int nhalf, bool st, bool ld, int fill, v4i (&accN)[2][2],
 	                int (&gN)[8], const v4i (&accP)[2][2], const int (&gP)[8]) {
+
 		const unsigned char *bp0 = btile + ((size_t)cur * kScanStage + half * kScanTN) * ROWB + frag_off;
 		const unsigned char *bp1 = bp0 + 16 * ROWB;
 		const int vn0 = nvn0, vn1 = nvn1;
@@ -452,7 +535,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 #endif
 			// (stores first, then every reload: a reload issued between two stores would make the
 			// next store's vmcnt wait cover it)
-#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 8)  // ... no staging
+#if (defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 8)) || MVDB_SCAN_DMA  // ... no staging / not through registers
 			if (false) {
 #else
 			if (st && (ks & 1) == 0 && (ks >> 1) < PIECES) stage_store_piece(ks >> 1, fill);
@@ -489,7 +572,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 		if ((tile % kScanPoll) == 0 && owner && my_qrow < a.nq)
 			ext_next = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		pass(tile, cur, 0, cur, 1, tile + D < ntiles, tile + D + 1 < ntiles, fill, accA, gA, accB, gB);
-		pass(tile, cur, 1, (NB >= 3 && more) ? nxt : -1, 0, false, false, 0, accB, gB, accA, gA);
+		pass(tile, cur, 1, (!MVDB_SCAN_DMA && NB >= 3 && more) ? nxt : -1, 0, false, false, fill, accB, gB, accA, gA);
 		if ((tile % kScanPoll) == 1 && __ballot(owner && ext_next < ext)) {  // a tighter bound from another split
 			if (owner && ext_next < ext) {
 				ext = ext_next;
@@ -500,8 +583,36 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 #ifdef MVDB_SCAN_DEBUG
 		const unsigned long long t_b = __builtin_amdgcn_s_memtime();
 #endif
+#if MVDB_SCAN_DMA
+		// tile + 1 must have landed: the waves that fetched it wait for their own operations (they
+		// have nothing newer in flight), the barrier covers the rest; tile + 2 (three buffers), fetched
+		// by the other group, stays in flight across the barrier; then the buffer of the tile just
+		// finished takes tile + NB
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef MVDB_SCAN_DEBUG
+		const unsigned long long t_1 = __builtin_amdgcn_s_memtime();
+		dbg_c[8] += t_1 - t_b;  // LDS reads drained
+#endif
+		if (((tile + 1) & 1) == dma_grp) scan_wait_vm<0>();
+#ifdef MVDB_SCAN_DEBUG
+		const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
+		dbg_c[9] += t_2 - t_1;  // own DMA landed
+#endif
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+#ifdef MVDB_SCAN_DEBUG
+		const unsigned long long t_3 = __builtin_amdgcn_s_memtime();
+		dbg_c[10] += t_3 - t_2;  // barrier
+#endif
+		if (more) prefetch(nxt, 0);
+		if (tile + NB < ntiles && ((tile + NB) & 1) == dma_grp) dma_issue(tile + NB, cur);
+#ifdef MVDB_SCAN_DEBUG
+		dbg_c[11] += __builtin_amdgcn_s_memtime() - t_3;  // prefetch + DMA issue
+#endif
+#else
 		__syncthreads();
 		if (NB < 3 && more) prefetch(nxt, 0);
+#endif
 #ifdef MVDB_SCAN_DEBUG
 		dbg_c[5] += __builtin_amdgcn_s_memtime() - t_b;
 #endif
@@ -518,7 +629,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 #ifdef MVDB_SCAN_DEBUG
 	dbg_c[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
 	if (lane == 0 && a.dbg)
-		for (int i = 0; i < 8; i++) atomicAdd(&a.dbg[i], dbg_c[i]);
+		for (int i = 0; i < 16; i++) atomicAdd(&a.dbg[i], dbg_c[i]);
 #endif
 
 	// ---- per-(query, split) partial lists, sorted ascending
@@ -592,8 +703,8 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(ScanArgs a, int slots_u
 // times as many nodes as everything before it -- produces ~k (r - 1) appends per query in
 // total, whatever S is.  Every level writes its own partial lists (slot = level * nsplit +
 // split); the final merge takes all of them.  No node is visited twice.
-constexpr int kScanLevel0 = 4096;   // nodes of the first level (no bound yet)
-constexpr int kScanLevelRatio = 4;  // each later level ends at ratio x its start
+constexpr int kScanLevel0 = 1024;   // nodes of the first level (no bound yet)
+constexpr int kScanLevelRatio = 8;  // each later level ends at ratio x its start
 constexpr int kScanMaxLevels = 16;
 
 // ends[i] = end of level i (multiples of kScanStage, last = N); returns the number of levels

@@ -23,7 +23,7 @@ b.init({"dim": dim, "m": 2, "ef": 4, "capacity": rows, "seed": 3})
 b.buildParallel(b8, 16)
 for _ in range(2):
     b.scanMany(q8, k, "l2")
-out = np.zeros(8, np.uint64)
+out = np.zeros(16, np.uint64)
 L = b._L
 L.mvdb_debug_scan_counters.argtypes = [C.c_void_p, C.c_void_p]
 assert L.mvdb_debug_scan_counters(b.handle, out.ctypes.data_as(C.c_void_p))
@@ -36,3 +36,4 @@ print(f"wave cycles: total {total_cyc:.3g}  slow path {100 * slow_cyc / total_cy
       f"stage store + barrier {100 * store_barrier_cyc / total_cyc:.1f}%  per tile {total_cyc / max(tiles, 1):.0f}")
 if os.environ.get("MVDB_SCAN_ABLATE_STAMPS"):
     print(f"end of tile per wave-tile: wait for loads {iters / tiles:.0f}  LDS stores {rows_flushed / tiles:.0f}  barrier {compact_cyc / tiles:.0f} cycles")
+print("end of tile, cycles per wave-pass: drain LDS reads %.0f  own DMA landed %.0f  barrier %.0f  prefetch + DMA issue %.0f" % tuple(int(x) / max(tiles, 1) for x in out[8:12]))

@@ -33,7 +33,7 @@ def stats(stage):
 
 
 ref = None
-for level0, ratio in ((4096, 4), (4096, 2), (8192, 2), (2048, 2), (2048, 4), (8192, 4), (4096, 8), (16384, 1 << 20), (4096, 3)):
+for level0, ratio in ((4096, 4), (2048, 4), (1024, 4), (512, 4), (4096, 8), (2048, 8), (1024, 8), (512, 8), (1024, 16), (2048, 16), (1024, 6), (2048, 6), (1024, 32)):
     os.environ["MVDB_SCAN_LEVEL0"] = str(level0)
     os.environ["MVDB_SCAN_RATIO"] = str(ratio)
     for _ in range(2):
