@@ -123,7 +123,10 @@ int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, do
 /* ---- float32 store (vectors.f32.bin, src/mini-vector-db.ts:1013-1036) ---- */
 /* Upload `rows` x dim f32 rows (row id at byte id*dim*4) for the rerank stage.
  * resident=1: copy into HBM (preloadVectors=true analogue).
- * resident=0: keep in pinned host memory, gathered over the host link. */
+ * resident=0: keep in pinned host memory, gathered over the host link (preloadVectors=false, the
+ *   reference's file mode).  As in the reference, a kept candidate whose row lies past the store is
+ *   skipped by the resident store (:1090) and is an error in file mode ("Vector store short read",
+ *   :1120-1124): the call that synchronises -- or mvdb_check_errors -- fails with that message. */
 int mvdb_attach_f32(mvdb_index *h, const float *base, int64_t rows, int resident);
 
 /* ---- stage 0: query prep (src/mini-vector-db.ts:963-984) ----------------- */
@@ -182,6 +185,18 @@ int mvdb_query_many_dev(mvdb_index *h, const float *d_q_f32, int nq, int topk, i
 int mvdb_query_many(mvdb_index *h, const float *q_f32, int nq, int topk, int ef_search, int ann_k,
                     const uint32_t *allow, int32_t *out_ids, double *out_l2, int32_t *out_n,
                     mvdb_query_counters *ctr);
+/* The same fused path with several batches in flight, for hosts that hold no device pointers
+ * (Node N-API, plain C).  The reference's searchMany (mini-vector-db.ts:560-655) is synchronous, so
+ * this pair has no single counterpart: submit = the body of searchMany up to and including the
+ * rerank, enqueued on the slot's own stream (host -> device copy of the queries, prep, traversal,
+ * rerank, device -> host copy of the results into pinned staging) and returns at once; wait blocks
+ * on that slot only and hands the results over.  slot 0..3; a slot holds one batch at a time;
+ * allow is copied before submit returns.  Do not change the index (insert / load / setResultsCap)
+ * while any slot is busy: submit refuses to upload then.  A traversal abort raised by any slot is
+ * reported by the next wait (one error word per handle). */
+int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, int topk, int ef_search,
+                           int ann_k, const uint32_t *allow);
+int mvdb_query_many_wait(mvdb_index *h, int slot, int32_t *out_ids, double *out_l2, int32_t *out_n);
 /* ef / annK derivation (mini-vector-db.ts:568-576) and the results-cap growth
  * rule ensureResultsCapAtLeast (:1160-1170), host-only helpers */
 void mvdb_derive_params(int topk_in, int base_ef_search, int rerank_multiplier, int max_ann_k, int *topk,

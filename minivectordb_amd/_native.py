@@ -61,6 +61,8 @@ SYMBOLS = [
     ("mvdb_rerank_many_dev", _i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_query_many_dev", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mvdb_query_many", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mvdb_query_many_submit", _i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    ("mvdb_query_many_wait", _i, [_vp, _i, _vp, _vp, _vp]),
     ("mvdb_derive_params", None, [_i, _i, _i, _i, _vp, _vp, _vp]),
     ("mvdb_ensure_results_cap_at_least", None, [_vp, _i]),
     ("mvdb_to_score", _d, [_d, _i]),

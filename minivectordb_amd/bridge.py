@@ -306,6 +306,28 @@ class HipBridge:
                                                 _ptr(allow), _ptr(out_ids), _ptr(out_l2), _ptr(out_n), _ptr(ctr)))
         return (out_ids, out_l2, out_n, ctr) if with_counters else (out_ids, out_l2, out_n)
 
+    # ---- several batches in flight from host buffers (mvdb_query_many_submit / _wait; slots 0..3)
+    def submitMany(self, slot: int, q_f32, topk: int, ef_search: int, ann_k: int, allow_bitmap=None):
+        q = self._rows(q_f32, np.float32, "submitMany")
+        allow = self._allow(allow_bitmap)
+        with self._lock:
+            self._check(self._L.mvdb_query_many_submit(self.handle, int(slot), _ptr(q), q.shape[0], int(topk),
+                                                       int(ef_search), int(ann_k), _ptr(allow)))
+        self._slot_shape = getattr(self, "_slot_shape", {})
+        self._slot_shape[int(slot)] = (q.shape[0], int(topk))
+
+    def waitMany(self, slot: int):
+        shape = getattr(self, "_slot_shape", {}).pop(int(slot), None)
+        if shape is None:
+            raise MvdbError(f"waitMany: nothing was submitted on slot {slot}")
+        nq, topk = shape
+        out_ids = np.full((nq, max(topk, 1)), -1, np.int32)
+        out_l2 = np.zeros((nq, max(topk, 1)), np.float64)
+        out_n = np.zeros(nq, np.int32)
+        with self._lock:
+            self._check(self._L.mvdb_query_many_wait(self.handle, int(slot), _ptr(out_ids), _ptr(out_l2), _ptr(out_n)))
+        return out_ids, out_l2, out_n
+
     def distMany(self, q_i8, ids, metric: str = "l2"):
         q = self._rows(q_i8, np.int8, "distMany")
         ids = np.ascontiguousarray(ids, np.int32)

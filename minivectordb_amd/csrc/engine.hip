@@ -342,6 +342,16 @@ struct mvdb_index {
 		unsigned vis_epoch = 0;        // stamp of the last launch on `visited` (VisitedSet): 1..255
 	} ss[kStreamSets];
 	int ss_next = 0;  // round-robin victim when every set is taken
+	// Host slots (mvdb_query_many_submit / _wait): a stream of its own, pinned host staging and device
+	// buffers per slot, so a host without device pointers (Node, plain C) keeps several batches in flight.
+	struct HostSlot {
+		hipStream_t stream = nullptr;
+		void *pin_in = nullptr, *pin_out = nullptr;
+		size_t pin_in_cap = 0, pin_out_cap = 0;
+		DevBuf d_in, d_ids, d_l2, d_n, d_allow;
+		int nq = 0, topk = 0;
+		bool busy = false;
+	} hs[kStreamSets];
 	DevBuf st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
 		st_misc, scan_part, prof_buf;
 
@@ -365,6 +375,14 @@ struct mvdb_index {
 		(void)hipFree(f32_dev);
 		if (f32_pinned) (void)hipHostFree(f32_pinned);
 		if (err_host) (void)hipHostFree(err_host);
+		for (auto &s : hs) {
+			if (s.stream) {
+				(void)hipStreamSynchronize(s.stream);
+				(void)hipStreamDestroy(s.stream);
+			}
+			if (s.pin_in) (void)hipHostFree(s.pin_in);
+			if (s.pin_out) (void)hipHostFree(s.pin_out);
+		}
 		for (auto &v : ev_pairs)
 			for (auto &pr : v) {
 				(void)hipEventDestroy(pr.first);
@@ -426,7 +444,10 @@ int check_device_errors(mvdb_index *h)
 	if (!h->err_host) return 1;
 	const int e = __atomic_exchange_n(h->err_host, 0, __ATOMIC_ACQ_REL);
 	if (e == 0) return 1;
-	h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
+	if (e & 1)
+		h->set_error("traversal kernel aborted a query (internal wave protocol failure)");
+	else  // mini-vector-db.ts:1120-1124: the file-mode reader throws when the store ends before a candidate's row
+		h->set_error("Vector store short read: a candidate's row lies past the end of the float32 store");
 	return 0;
 }
 
@@ -1136,6 +1157,8 @@ int mvdb_rerank_many_dev(mvdb_index *h, const float *d_q_f32, int nq, const int3
 	a.out_ids = d_out_ids;
 	a.out_l2 = d_out_l2;
 	a.out_n = d_out_n;
+	a.err = h->err_dev;
+	a.strict_store = h->f32_pinned != nullptr;  // file mode: a missing row is an error, not a skip
 	const int cap = std::min(stride, ann_k);
 	// mvdb_set_tuning(h, .., 2): small workgroups that fit beside a running traversal (batches in flight)
 	const int waves = h->rerank_waves == 2 ? 2 : kRerankWavesDefault;
@@ -1189,6 +1212,7 @@ int mvdb_rerank_many(mvdb_index *h, const float *q_f32, int nq, const int32_t *c
 	if (!mvdb_rerank_many_dev(h, d_q, nq, d_cand, d_cnt, stride, ann_k, d_allow, topk, d_oi, d_ol, d_on, nullptr))
 		return 0;
 	HIP_OK(h, hipDeviceSynchronize());
+	if (!check_device_errors(h)) return 0;
 	HIP_OK(h, hipMemcpy(out_n, d_on, (size_t)nq * 4, hipMemcpyDeviceToHost));
 	if (topk > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_oi, (size_t)nq * topk * 4, hipMemcpyDeviceToHost));
@@ -1298,6 +1322,110 @@ int mvdb_query_many(mvdb_index *h, const float *q_f32, int nq, int topk, int ef_
 		HIP_OK(h, hipMemcpy(out_l2, d_ol, (size_t)nq * topk * 8, hipMemcpyDeviceToHost));
 	}
 	if (ctr) HIP_OK(h, hipMemcpy(ctr, d_ctr, (size_t)nq * sizeof(mvdb_query_counters), hipMemcpyDeviceToHost));
+	return 1;
+}
+
+// ---- several batches in flight from a host without device pointers
+int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, int topk, int ef_search, int ann_k,
+                           const uint32_t *allow)
+{
+	if (slot < 0 || slot >= kStreamSets) {
+		h->set_error("mvdb_query_many_submit: slot must be 0..3");
+		return 0;
+	}
+	if (nq < 0 || topk < 0) {
+		h->set_error("mvdb_query_many_submit: negative nq / topk");
+		return 0;
+	}
+	if (h->dev.built_version != h->g.version)
+		for (const auto &o : h->hs)
+			if (o.busy) {  // the upload would move device memory under the batches in flight
+				h->set_error("mvdb_query_many_submit: the index changed while batches are in flight; wait for every slot first");
+				return 0;
+			}
+	if (!ensure_uploaded(h)) return 0;
+	mvdb_index::HostSlot &s = h->hs[slot];
+	if (s.busy) {
+		h->set_error("mvdb_query_many_submit: slot still holds a batch (call mvdb_query_many_wait first)");
+		return 0;
+	}
+	if (!s.stream) HIP_OK(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+	const size_t nqd = (size_t)nq * h->cfg.dim;
+	const int tk = std::max(topk, 1);
+	const size_t in_bytes = std::max<size_t>(nqd * 4, 16);
+	const size_t out_bytes = (size_t)std::max(nq, 1) * tk * 12 + (size_t)std::max(nq, 1) * 4 + 16;
+	if (s.pin_in_cap < in_bytes) {
+		if (s.pin_in) HIP_OK(h, hipHostFree(s.pin_in));
+		s.pin_in = nullptr;
+		s.pin_in_cap = 0;
+		HIP_OK(h, hipHostMalloc(&s.pin_in, in_bytes, hipHostMallocDefault));
+		s.pin_in_cap = in_bytes;
+	}
+	if (s.pin_out_cap < out_bytes) {
+		if (s.pin_out) HIP_OK(h, hipHostFree(s.pin_out));
+		s.pin_out = nullptr;
+		s.pin_out_cap = 0;
+		HIP_OK(h, hipHostMalloc(&s.pin_out, out_bytes, hipHostMallocDefault));
+		s.pin_out_cap = out_bytes;
+	}
+	s.nq = nq;
+	s.topk = topk;
+	if (nq == 0) {
+		s.busy = true;
+		return 1;
+	}
+	float *d_in = static_cast<float *>(s.d_in.need(nqd * 4));
+	int32_t *d_oi = static_cast<int32_t *>(s.d_ids.need((size_t)nq * tk * 4));
+	double *d_ol = static_cast<double *>(s.d_l2.need((size_t)nq * tk * 8));
+	int32_t *d_on = static_cast<int32_t *>(s.d_n.need((size_t)nq * 4));
+	uint32_t *d_allow = nullptr;
+	if (!d_in || !d_oi || !d_ol || !d_on) {
+		h->set_error("out of device memory (query slot staging)");
+		return 0;
+	}
+	if (allow) {
+		const size_t words = ((size_t)std::max<int64_t>(h->g.max_elements, 1) + 31) / 32;
+		d_allow = static_cast<uint32_t *>(s.d_allow.need(words * 4));
+		if (!d_allow) {
+			h->set_error("out of device memory (allow bitmap)");
+			return 0;
+		}
+		// pageable source: the copy is staged by the runtime before the call returns
+		HIP_OK(h, hipMemcpyAsync(d_allow, allow, words * 4, hipMemcpyHostToDevice, s.stream));
+	}
+	std::memcpy(s.pin_in, q_f32, nqd * 4);
+	HIP_OK(h, hipMemcpyAsync(d_in, s.pin_in, nqd * 4, hipMemcpyHostToDevice, s.stream));
+	if (!mvdb_query_many_dev(h, d_in, nq, topk, ef_search, ann_k, d_allow, d_oi, d_ol, d_on, nullptr, s.stream)) return 0;
+	unsigned char *po = static_cast<unsigned char *>(s.pin_out);
+	HIP_OK(h, hipMemcpyAsync(po, d_ol, (size_t)nq * tk * 8, hipMemcpyDeviceToHost, s.stream));
+	HIP_OK(h, hipMemcpyAsync(po + (size_t)nq * tk * 8, d_oi, (size_t)nq * tk * 4, hipMemcpyDeviceToHost, s.stream));
+	HIP_OK(h, hipMemcpyAsync(po + (size_t)nq * tk * 12, d_on, (size_t)nq * 4, hipMemcpyDeviceToHost, s.stream));
+	s.busy = true;
+	return 1;
+}
+
+int mvdb_query_many_wait(mvdb_index *h, int slot, int32_t *out_ids, double *out_l2, int32_t *out_n)
+{
+	if (slot < 0 || slot >= kStreamSets) {
+		h->set_error("mvdb_query_many_wait: slot must be 0..3");
+		return 0;
+	}
+	mvdb_index::HostSlot &s = h->hs[slot];
+	if (!s.busy) {
+		h->set_error("mvdb_query_many_wait: nothing was submitted on this slot");
+		return 0;
+	}
+	s.busy = false;
+	if (s.nq == 0) return 1;
+	HIP_OK(h, hipStreamSynchronize(s.stream));
+	if (!check_device_errors(h)) return 0;
+	const int tk = std::max(s.topk, 1);
+	const unsigned char *po = static_cast<const unsigned char *>(s.pin_out);
+	if (s.topk > 0) {
+		std::memcpy(out_l2, po, (size_t)s.nq * s.topk * 8);
+		std::memcpy(out_ids, po + (size_t)s.nq * tk * 8, (size_t)s.nq * s.topk * 4);
+	}
+	std::memcpy(out_n, po + (size_t)s.nq * tk * 12, (size_t)s.nq * 4);
 	return 1;
 }
 

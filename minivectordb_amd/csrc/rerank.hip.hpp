@@ -48,6 +48,11 @@ struct RerankArgs {
 	int32_t *out_ids;         // nq x topk
 	double *out_l2;           // nq x topk
 	int32_t *out_n;           // nq
+	// File mode (preloadVectors = false, the store stays on the host): a kept candidate whose row lies past the
+	// store is an ERROR there (readF32Vectors, mini-vector-db.ts:1120-1124 "Vector store short read"), where the
+	// preloaded store skips it (:1090).  strict_store raises bit 1 of the handle's error word for it.
+	int *err;
+	int strict_store;
 };
 
 // LDS: q_s[dim_pad] f32 | tiles[waves][64*144] | key_l2[cap] f64 | key_id[cap] i32 | misc
@@ -144,6 +149,8 @@ __global__ __launch_bounds__(kRerankWaves * 64) void rerank_kernel(RerankArgs a,
 		const int my = c0 + lane;
 		const int my_id = my < nkept ? key_id[my] : -1;
 		const bool my_ok = my_id >= 0 && (int64_t)my_id < a.rows;  // rows beyond the store are skipped (:1090)
+		if (a.strict_store && a.err && my_id >= 0 && (int64_t)my_id >= a.rows)
+			__hip_atomic_fetch_or(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		// pass p brings rows p*kTileRowsPerPass+g, 16 B at column piece s
 		const float *rowp[kTilePasses];
 #pragma unroll

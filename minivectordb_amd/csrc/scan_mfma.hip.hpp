@@ -598,7 +598,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 		const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
 		dbg_c[9] += t_2 - t_1;  // own DMA landed
 #endif
+#if !(defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 32))  // timing experiment (racy, wrong results): waves never wait for each other
 		__builtin_amdgcn_s_barrier();
+#endif
 		asm volatile("" ::: "memory");
 #ifdef MVDB_SCAN_DEBUG
 		const unsigned long long t_3 = __builtin_amdgcn_s_memtime();

@@ -151,6 +151,39 @@ class HipBridge {
 	async queryMany(qF32, nq, topK, efSearch, annK, allowBitmap = null) {
 		return this.withLock(() => native.queryMany(this.h, qF32, nq | 0, topK | 0, efSearch | 0, annK | 0, allowBitmap));
 	}
+	// Several batches in flight (the engine runs each slot on its own stream; mvdb_query_many_submit / _wait).
+	// `batches`: array of Float32Array, each nq_i x dim; returns the per-batch {ids, l2, n} in order.  The whole
+	// sweep holds the bridge lock, like every other call that touches the engine (wasm-bridge.ts:112-129).
+	async queryManyBatches(batches, topK, efSearch, annK, allowBitmap = null, inFlight = 3) {
+		return this.withLock(() => {
+			const dim = this.currentConfig.dim | 0;
+			const depth = Math.max(1, Math.min(4, inFlight | 0));
+			const out = new Array(batches.length);
+			const nqOf = (b) => {
+				if (!(b instanceof Float32Array) || b.length % dim !== 0) throw new TypeError(`queryManyBatches: every batch must be a Float32Array of nq x ${dim} values`);
+				return b.length / dim;
+			};
+			const pending = []; // {slot, i, nq}
+			let error = null;
+			for (let i = 0; i < batches.length && !error; i++) {
+				if (pending.length === depth) {
+					const p = pending.shift();
+					out[p.i] = native.waitMany(this.h, p.slot, p.nq, topK | 0);
+				}
+				const slot = i % depth;
+				try {
+					const nq = nqOf(batches[i]);
+					native.submitMany(this.h, slot, batches[i], nq, topK | 0, efSearch | 0, annK | 0, allowBitmap);
+					pending.push({ slot, i, nq });
+				} catch (e) { error = e; }
+			}
+			for (const p of pending) { // drain every slot, also after an error, so that none stays busy
+				try { out[p.i] = native.waitMany(this.h, p.slot, p.nq, topK | 0); } catch (e) { error = error || e; }
+			}
+			if (error) throw error;
+			return out;
+		});
+	}
 	close() { if (this.h) { native.destroy(this.h); this.h = null; } }
 }
 

@@ -286,6 +286,52 @@ static napi_value QueryMany(napi_env env, napi_callback_info info)
 	NAPI_OK(napi_set_named_property(env, out, "n", t_n));
 	return out;
 }
+/* submitMany(h, slot, Float32Array q, nq, topk, efSearch, annK, Uint32Array allow | null): enqueue a batch on the
+ * slot's stream and return (mvdb_query_many_submit) */
+static napi_value SubmitMany(napi_env env, napi_callback_info info)
+{
+	size_t argc = 8, nb, nba;
+	napi_value a[8];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, a, NULL, NULL));
+	mvdb_index *h = get_handle(env, a[0]);
+	if (!h) return NULL;
+	int slot = get_i32(env, a[1]);
+	const float *q = (const float *)bytes_of(env, a[2], &nb);
+	int nq = get_i32(env, a[3]), topk = get_i32(env, a[4]), ef = get_i32(env, a[5]), annk = get_i32(env, a[6]);
+	const uint32_t *allow = argc > 7 ? (const uint32_t *)bytes_of(env, a[7], &nba) : NULL;
+	if (!q || !rows_fit(h, nq, 4, nb)) return throw_type(env, "submitMany: q must hold nq rows of dim float32 values");
+	if (topk < 0) return throw_type(env, "submitMany: topk must not be negative");
+	if (allow && !allow_fits(h, nba)) return throw_type(env, "submitMany: allow bitmap shorter than ceil(max_elements / 32) words");
+	if (!mvdb_query_many_submit(h, slot, q, nq, topk, ef, annk, allow)) return throw_last(env, h);
+	return NULL;
+}
+/* waitMany(h, slot, nq, topk) -> {ids, l2, n} of the batch submitted on the slot (the same nq / topk) */
+static napi_value WaitMany(napi_env env, napi_callback_info info)
+{
+	size_t argc = 4;
+	napi_value a[4];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, a, NULL, NULL));
+	mvdb_index *h = get_handle(env, a[0]);
+	if (!h) return NULL;
+	int slot = get_i32(env, a[1]), nq = get_i32(env, a[2]), topk = get_i32(env, a[3]);
+	if (nq < 0 || topk < 0) return throw_type(env, "waitMany: nq / topk must not be negative");
+	size_t tk = topk > 0 ? (size_t)topk : 1;
+	void *ids, *l2, *n;
+	napi_value t_ids = make_typed(env, napi_int32_array, (size_t)nq * tk, 4, &ids);
+	napi_value t_l2 = make_typed(env, napi_float64_array, (size_t)nq * tk, 8, &l2);
+	napi_value t_n = make_typed(env, napi_int32_array, (size_t)nq, 4, &n);
+	if (!t_ids || !t_l2 || !t_n) {
+		napi_throw_error(env, NULL, "waitMany: allocation failed");
+		return NULL;
+	}
+	if (!mvdb_query_many_wait(h, slot, (int32_t *)ids, (double *)l2, (int32_t *)n)) return throw_last(env, h);
+	napi_value out;
+	NAPI_OK(napi_create_object(env, &out));
+	NAPI_OK(napi_set_named_property(env, out, "ids", t_ids));
+	NAPI_OK(napi_set_named_property(env, out, "l2", t_l2));
+	NAPI_OK(napi_set_named_property(env, out, "n", t_n));
+	return out;
+}
 /* prepareQueries(h, Float32Array q, nq) -> {norm: Float32Array, i8: Int8Array} (normalise + quantise) */
 static napi_value PrepareQueries(napi_env env, napi_callback_info info)
 {
@@ -329,7 +375,8 @@ static napi_value Init(napi_env env, napi_value exports)
 	           {"elementCount", ElementCount}, {"setEfSearch", SetEfSearch}, {"setResultsCap", SetResultsCap},
 	           {"insertManyPacked", InsertManyPacked}, {"loadDump", LoadDump}, {"saveDump", SaveDump},
 	           {"searchMany", SearchMany}, {"attachF32", AttachF32}, {"queryMany", QueryMany},
-	           {"prepareQueries", PrepareQueries}, {"deviceAvailable", DeviceAvailable}};
+	           {"prepareQueries", PrepareQueries}, {"deviceAvailable", DeviceAvailable}, {"submitMany", SubmitMany},
+	           {"waitMany", WaitMany}};
 	for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {
 		napi_value f;
 		if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

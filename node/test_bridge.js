@@ -57,6 +57,24 @@ function oneHotI8(dim, i) { const v = new Int8Array(dim); v[i % dim] = 127; retu
 	let shortAllow = "";
 	try { await b.queryMany(q, 4, 3, 140, 360, new Uint32Array(2)); } catch (e) { shortAllow = String(e.message); }
 	assert(/allow bitmap/.test(shortAllow), "a short allow bitmap must throw");
+	// several batches in flight: 7 batches of different sizes over 3 slots answer exactly like one-at-a-time queryMany
+	const batches = [];
+	for (let bi = 0; bi < 7; bi++) {
+		const nqb = 1 + (bi * 5) % 9;
+		const qb = new Float32Array(nqb * dim);
+		for (let i = 0; i < nqb; i++) { qb[i * dim + ((bi * 11 + i) % N)] = 1 + bi; qb[i * dim + ((bi * 3 + i + 1) % N)] = 0.25; }
+		batches.push(qb);
+	}
+	const piped = await b.queryManyBatches(batches, 5, 140, 360, null, 3);
+	for (let bi = 0; bi < 7; bi++) {
+		const single = await b.queryMany(batches[bi], batches[bi].length / dim, 5, 140, 360, null);
+		for (const key of ["ids", "l2", "n"]) assert(JSON.stringify(Array.from(piped[bi][key])) === JSON.stringify(Array.from(single[key])), `queryManyBatches batch ${bi} ${key}`);
+	}
+	let badBatch = "";
+	try { await b.queryManyBatches([batches[0], new Float32Array(dim + 1)], 5, 140, 360); } catch (e) { badBatch = String(e.message); }
+	assert(badBatch.length > 0, "a ragged batch must throw");
+	const after = await b.queryManyBatches([batches[1]], 5, 140, 360); // no slot was left busy by the failed sweep
+	assert(after.length === 1 && after[0].n.length === batches[1].length / dim, "slots are free again after an error");
 	b.close(); b2.close(); b3.close();
 	console.log("node bridge test passed");
 })().catch((e) => { console.error("FAILED:", e); process.exit(1); });

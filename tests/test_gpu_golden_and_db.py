@@ -246,3 +246,46 @@ def test_pipelined_batches_equal_single_stream(gpu):
         r_ids, r_l2, r_n = s.query_many(q, 140, 1200)
         torch.cuda.synchronize(dev)
         assert torch.equal(ids, r_ids) and torch.equal(l2, r_l2) and torch.equal(n, r_n)
+
+
+def test_host_slots_keep_batches_in_flight(gpu):
+    """mvdb_query_many_submit / _wait (the path a Node or C host uses to keep several batches in flight): results
+    equal the oracle's searchMany restatement and the one-at-a-time mvdb_query_many, bit for bit; ragged batch
+    sizes, an allow bitmap on one slot, slots reused; misuse is an error, not undefined behaviour."""
+    from minivectordb_amd import MvdbError, derive_search_params, resolve_preset
+    from tests._data import bridge_from_dump, built_index, gaussian_unit
+    dump, base, b8 = built_index(4000, 384, "balanced")
+    b = bridge_from_dump(dump, 384, "balanced")
+    b.attachF32(base, resident=True)
+    tk, ef, ann_k = derive_search_params(10, resolve_preset("balanced"))
+    allow = np.zeros((4000 + 31) // 32, np.uint32)
+    allow[::2] = 0xFFFFFFFF
+    sizes = [200, 37, 1, 128, 200, 64, 5]
+    batches = [gaussian_unit(n, 384, 300 + i) for i, n in enumerate(sizes)]
+    masks = [allow if i == 3 else None for i in range(len(sizes))]
+    got, pending = [None] * len(sizes), []
+    for i, q in enumerate(batches):
+        if len(pending) == 3:
+            j, slot = pending.pop(0)
+            got[j] = b.waitMany(slot)
+        b.submitMany(i % 3, q, tk, ef, ann_k, masks[i])
+        pending.append((i, i % 3))
+    for j, slot in pending:
+        got[j] = b.waitMany(slot)
+    for q, m, (ids, l2, n) in zip(batches, masks, got):
+        r_ids, r_l2, r_n = b.queryMany(q, tk, ef, ann_k, m)
+        assert np.array_equal(n, r_n)
+        for qi in range(q.shape[0]):
+            assert np.array_equal(ids[qi, :n[qi]], r_ids[qi, :n[qi]])
+            assert np.array_equal(l2[qi, :n[qi]].view(np.uint64), r_l2[qi, :n[qi]].view(np.uint64))
+    # misuse
+    with pytest.raises(MvdbError):
+        b.waitMany(1)                                  # nothing submitted
+    b.submitMany(2, batches[1], tk, ef, ann_k)
+    with pytest.raises(MvdbError):
+        b.submitMany(2, batches[2], tk, ef, ann_k)     # slot busy
+    with pytest.raises(MvdbError):
+        b.submitMany(4, batches[2], tk, ef, ann_k)     # no such slot
+    ids, l2, n = b.waitMany(2)
+    assert np.array_equal(n, got[1][2])
+    b.close()

@@ -6,6 +6,7 @@ f64 (stricter than the 1e-5 relative the north star allows) with identical topK 
 import numpy as np
 import pytest
 
+from minivectordb_amd import MvdbError
 from oracle import oracle as O
 from tests._data import bridge_from_dump, built_index, gaussian_unit, oracle_from_dump
 
@@ -87,11 +88,25 @@ def test_rerank_bit_exact(small):
     oi, ol, on = O.rerank_many(qf, base, ids, cnt2, 300, 17, allow)
     assert np.array_equal(gn, on) and np.array_equal(gi, oi)
     assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
-    b.attachF32(base[:2500], resident=False)                            # ids beyond the store are skipped
+    b.attachF32(base[:2500], resident=True)     # preloaded store: ids beyond it are skipped (mini-vector-db.ts:1090)
     gi, gl, gn = b.rerankMany(qf, ids, cnt, 1200, 10)
     oi, ol, on = O.rerank_many(qf, base[:2500], ids, cnt, 1200, 10)
     assert np.array_equal(gn, on) and np.array_equal(gi, oi)
     assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
+    # file mode (store on the host): the reference's reader throws "Vector store short read" (:1120-1124)
+    b.attachF32(base[:2500], resident=False)
+    with pytest.raises(MvdbError, match="short read"):
+        b.rerankMany(qf, ids, cnt, 1200, 10)
+    keep = np.zeros((4000 + 31) // 32, np.uint32)                       # a filter that keeps only stored rows: no error
+    keep[:2500 // 32] = 0xFFFFFFFF
+    gi, gl, gn = b.rerankMany(qf, ids, cnt, 1200, 10, keep)
+    oi, ol, on = O.rerank_many(qf, base[:2500], ids, cnt, 1200, 10, keep)
+    assert np.array_equal(gn, on) and np.array_equal(gi, oi)
+    assert np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
+    b.attachF32(base, resident=False)                                   # a complete host store answers like the resident one
+    gi, gl, gn = b.rerankMany(qf, ids, cnt, 1200, 10)
+    oi, ol, on = O.rerank_many(qf, base, ids, cnt, 1200, 10)
+    assert np.array_equal(gn, on) and np.array_equal(gi, oi)
 
 
 def test_query_many_matches_reference_pipeline(small):
