@@ -268,8 +268,13 @@ class Pipeline:
             return None
         self.torch.cuda.synchronize(self.dev)
         # batches on different streams may complete out of submission order: sort the completion times first
+        # and with D batches in flight they complete in clumps: the step time is the median over windows of D
+        # consecutive completions, (t[j + D] - t[j]) / D
         t = sorted(self.events[0].elapsed_time(e) for e in self.events)
-        gaps = sorted(t[j + 1] - t[j] for j in range(len(t) - 1))
+        D = max(self.args.in_flight, 1)
+        if len(t) <= D:
+            return None
+        gaps = sorted((t[j + D] - t[j]) / D for j in range(len(t) - D))
         return float(gaps[len(gaps) // 2])
 
     def pcie_inclusive(self, steps):
@@ -302,6 +307,37 @@ class Pipeline:
         s.drain()
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t0
+
+    def host_slots(self, steps):
+        """The path a host without device pointers uses (Node N-API, plain C): mvdb_query_many_submit / _wait on
+        pageable host buffers, D slots in flight.  Results of the first round are checked against the device path."""
+        b, D = self.bridge, max(min(self.args.in_flight, 4), 1)
+        pending = []
+
+        def run(n, keep=None):
+            for j in range(n):
+                if len(pending) == D:
+                    jj, slot = pending.pop(0)
+                    r = b.waitMany(slot)
+                    if keep is not None:
+                        keep[jj] = r
+                b.submitMany(j % D, self.q_host[j % self.nb], self.tk, self.ef_search, self.ann_k)
+                pending.append((j, j % D))
+            while pending:
+                jj, slot = pending.pop(0)
+                r = b.waitMany(slot)
+                if keep is not None:
+                    keep[jj] = r
+        first = {}
+        run(min(3, self.nb), first)
+        ids, l2, n = first[0]
+        r_ids, r_l2, r_n = (x.cpu().numpy() for x in self.ref[0])
+        same = bool(np.array_equal(n, r_n) and all(
+            np.array_equal(ids[q, :n[q]], r_ids[q, :n[q]]) and
+            np.array_equal(l2[q, :n[q]].view(np.uint64), np.ascontiguousarray(r_l2[q, :n[q]]).view(np.uint64)) for q in range(self.nq)))
+        t0 = time.perf_counter()
+        run(steps)
+        return time.perf_counter() - t0, same
 
     def recall(self):
         """recall@10 of batch 0 against the exact float32 top-10 (over ALL shards when sharded)."""
@@ -429,6 +465,12 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                                         ms_per_step=round(el / args.steps * 1e3, 4),
                                         what="each step copies its queries from pinned host memory and its results back")
         s.check()
+        if not sharded:
+            el, same = pl.host_slots(args.steps)
+            extras["host_slots"] = dict(value=round(pl.nq / (el / args.steps), 2), unit="queries/s",
+                                        ms_per_step=round(el / args.steps * 1e3, 4), same_as_device_path=same,
+                                        what="mvdb_query_many_submit/_wait on pageable host buffers (the Node / plain C "
+                                             "host's way to keep batches in flight), copies inside")
     if args.sustain_s > 0:
         k = max(args.steps, int(math.ceil(args.sustain_s / max(elapsed / args.steps, 1e-6))))
         el = pl.timed(k)
