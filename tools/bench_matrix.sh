@@ -6,7 +6,7 @@ run --in-flight 2
 run --in-flight 3
 run --in-flight 4
 run --in-flight 1
-MVDB_TRAVERSE_WAVES=1 run --in-flight 2
-MVDB_TRAVERSE_WAVES=1 run --in-flight 1
+run --in-flight 2 --traverse-waves 1
+run --in-flight 1 --traverse-waves 1
 run --in-flight 2 --nq 2048
-MVDB_TRAVERSE_WAVES=1 run --in-flight 2 --nq 2048
+run --in-flight 2 --nq 2048 --traverse-waves 1
