@@ -210,3 +210,25 @@ def test_scan_many_512d_bit_exact(gpu):
             assert np.array_equal(gv, ov), (metric, k)
     with pytest.raises(Exception):
         b.scanMany(q8[:4], 33, "l2")                         # k beyond the documented maximum is an error, not a truncation
+
+
+@pytest.mark.parametrize("dim,n", [(100, 5000), (200, 3001), (320, 2111), (16, 1500)])
+def test_scan_many_partial_rows(gpu, dim, n):
+    """Dimensions whose padded row is shorter than the kernel's k-step grid (zero-filled pieces of the LDS-DMA
+    staging, 6- and 2-k-step instantiations), node counts that end inside a staged tile, ragged query count."""
+    from minivectordb_amd import HipBridge
+    rng = np.random.default_rng(dim)
+    b8 = rng.integers(-127, 128, (n, dim), dtype=np.int16).astype(np.int8)
+    ix = O.OracleIndex(dim, 2, 4, n, seed=5)
+    ix.insert_many(np.arange(n, dtype=np.int32), b8)
+    b = HipBridge()
+    b.init(dict(dim=dim, m=2, ef=4, capacity=8, seed=1))
+    b.loadBytes(ix.save_bytes())
+    q8 = rng.integers(-127, 128, (77, dim), dtype=np.int16).astype(np.int8)
+    for metric in ("l2", "dot"):
+        for k in (3, 17):
+            gi, gv, gc = b.scanMany(q8, k, metric)
+            oi, ov, oc = ix.scan_many(q8, k, metric, threads=8)
+            assert np.array_equal(gc, oc)
+            assert np.array_equal(gi, oi), (metric, k)
+            assert np.array_equal(gv, ov), (metric, k)
