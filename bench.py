@@ -649,7 +649,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="hnsw", choices=["hnsw", "scan"])
-    ap.add_argument("--n", type=int, default=None, help="vectors per index (per shard when sharded); default 1M")
+    # (--rows: torchrun's own parser trips over "--n" in the script's arguments)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=None, help="vectors per index (per shard when sharded); default 1M")
     ap.add_argument("--nq", type=int, default=None, help="queries per batch (default 1000; scan: 4096)")
     ap.add_argument("--dim", type=int, default=None, help="default 384 (scan: 512)")
     ap.add_argument("--preset", default="balanced")
@@ -668,6 +669,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
     ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1, 2, 3], help="0 = the engine's default")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="wiring rehearsal of the N>1 path on a one-GPU box: every rank uses cuda:0 and the exchange "
+                         "goes over gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing")
     args = ap.parse_args()
     scan = args.workload == "scan"
     args.n = args.n or 1_000_000
@@ -682,9 +686,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl", rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(90, exit=True)  # a rehearsal that hangs says where
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     out = (run_scan if scan else run_hnsw)(args, torch, dist, dev, rank, world)

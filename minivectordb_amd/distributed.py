@@ -56,8 +56,14 @@ def gather_blocks(block: torch.Tensor, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     block = block.contiguous()
     full = torch.empty((world, block.numel()), dtype=torch.uint8, device=block.device)
-    if block.is_cuda:
-        dist.all_gather_into_tensor(full, block, group=group)
+    if block.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo is the CPU backend (tests, one-GPU rehearsals of the N>1 wiring): stage through the host
+        host = torch.empty((world, block.numel()), dtype=torch.uint8)
+        dist.all_gather(list(host.unbind(0)), block.cpu(), group=group)
+        full.copy_(host)
+    elif block.is_cuda:
+        # RCCL; flat output = the ranks' blocks back to back
+        dist.all_gather_into_tensor(full.view(-1), block.view(-1), group=group)
     else:
         dist.all_gather(list(full.unbind(0)), block, group=group)
     return full
