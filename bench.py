@@ -170,6 +170,7 @@ class Pipeline:
         q_seed = 54321 + (rank if (world > 1 and not sharded) else 0)
         self.q_host = make_queries(self.nb, self.nq, self.dim, q_seed, self.base, clustered)
         self.q_dev = torch.from_numpy(self.q_host).to(dev)
+        self.bridge.setVisitedMode(args.visited_mode)
         self.searcher = ResidentSearcher(self.bridge, self.nq, self.tk, dev)
         self.step_i = 0
         self.events = []
@@ -669,6 +670,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
     ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1, 2, 3], help="0 = the engine's default")
+    ap.add_argument("--visited-mode", type=int, default=0, choices=[0, 1, 2],
+                    help="visited-bitmap clean-up: 0 / 1 memset per launch (default), 2 the kernel's log-and-clear (measured slower)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="wiring rehearsal of the N>1 path on a one-GPU box: every rank uses cuda:0 and the exchange "
                          "goes over gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing")

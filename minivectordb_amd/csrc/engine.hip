@@ -336,7 +336,9 @@ struct mvdb_index {
 	struct StreamScratch {
 		hipStream_t stream = nullptr;
 		bool used = false;
-		DevBuf visited, qf, q8, ids, dist, cnt;
+		DevBuf visited, vis_log, qf, q8, ids, dist, cnt;
+		bool vis_clean = false;        // the first vis_clean_bytes of `visited` are zero (log mode leaves them so)
+		size_t vis_clean_bytes = 0;
 		void *vis_seen_ptr = nullptr;  // the allocation (pointer, capacity) `vis_epoch` counts launches of
 		size_t vis_seen_cap = 0;
 		unsigned vis_epoch = 0;        // stamp of the last launch on `visited` (VisitedSet): 1..255
@@ -358,6 +360,10 @@ struct mvdb_index {
 	// tuning knobs of the timed path (mvdb_set_tuning); 0 = the engine's default
 	int traverse_waves = 0;  // 1, 2 or 3 waves per query
 	int rerank_waves = 0;    // 2 or 4 waves per rerank workgroup
+	// visited-set clean-up (mvdb_set_visited_mode): 0 / 1 = one memset per launch (the default: measured faster at
+	// 1 M and at 10 M nodes), 2 = the kernel's log-and-clear
+	int visited_mode = 0;
+	int visited_log_cap = 0;  // ids per query, 0 = kVisitedLogCap
 	// error word the kernels raise (host-pinned, device-mapped): bit 0 = a traversal aborted a query
 	int *err_host = nullptr;
 	int *err_dev = nullptr;
@@ -952,6 +958,8 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	a.set_only = set_only ? 1 : 0;
 	a.vis_stride = visited_stride_bytes(h->g.max_elements);
 	a.epoch = 1;
+	a.vis_log = nullptr;  // memset mode unless the caller sets a log up
+	a.vis_log_cap = 0;
 }
 
 mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
@@ -972,6 +980,8 @@ mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
 	c.stream = s;
 	return &c;
 }
+
+constexpr int kVisitedLogCap = 64 << 10;                    // logged ids per query (a balanced query marks ~18 k)
 
 // shared by mvdb_search_many_dev (sorted lists, the bridge contract) and the fused query path
 // (set_only: see TraverseArgs)
@@ -1000,15 +1010,36 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		h->set_error("out of device memory (visited sets)");
 		return 0;
 	}
+	// bitmap clean-up: per-launch memset, or the kernel's own log-and-clear (VisitedLog) for large indexes
+	const bool log_mode = !MVDB_VISITED_STAMPS && h->visited_mode == 2;
+	a.vis_log = nullptr;
+	a.vis_log_cap = h->visited_log_cap > 0 ? h->visited_log_cap : kVisitedLogCap;
+	if (log_mode) {
+		a.vis_log = static_cast<uint32_t *>(sc->vis_log.need((size_t)slab * (size_t)a.vis_log_cap * 4));
+		if (!a.vis_log) {
+			h->set_error("out of device memory (visited logs)");
+			return 0;
+		}
+	}
 	for (int q0 = 0; q0 < nq; q0 += slab) {
 		const int n = std::min(slab, nq - q0);
-		// a fresh allocation, or the epoch wrapping after 255 launches, clears the whole buffer; otherwise the
-		// next epoch makes every stamp of earlier launches read as "not visited" (nothing to clear per batch)
-		if (!MVDB_VISITED_STAMPS || sc->vis_seen_ptr != vis || sc->vis_seen_cap != sc->visited.cap || sc->vis_epoch >= 255) {
-			HIP_OK(h, hipMemsetAsync(vis, 0, MVDB_VISITED_STAMPS ? sc->visited.cap : (size_t)n * a.vis_stride, s));
+		const size_t need = (size_t)n * a.vis_stride;
+		if (log_mode) {
+			// zero once after (re)allocation or after a memset-mode launch; every log-mode launch leaves it zero
+			if (!sc->vis_clean || sc->vis_seen_ptr != vis || sc->vis_clean_bytes < need) {
+				HIP_OK(h, hipMemsetAsync(vis, 0, need, s));
+				sc->vis_seen_ptr = vis;
+				sc->vis_clean = true;
+				sc->vis_clean_bytes = need;
+			}
+		} else if (!MVDB_VISITED_STAMPS || sc->vis_seen_ptr != vis || sc->vis_seen_cap != sc->visited.cap || sc->vis_epoch >= 255) {
+			// a fresh allocation, or the epoch wrapping after 255 launches, clears the whole buffer; otherwise the
+			// next epoch makes every stamp of earlier launches read as "not visited" (nothing to clear per batch)
+			HIP_OK(h, hipMemsetAsync(vis, 0, MVDB_VISITED_STAMPS ? sc->visited.cap : need, s));
 			sc->vis_seen_ptr = vis;
 			sc->vis_seen_cap = sc->visited.cap;
 			sc->vis_epoch = 0;
+			sc->vis_clean = false;  // the launch leaves its marks behind
 		}
 		a.epoch = ++sc->vis_epoch;
 		StageTimer t(h, 1, s);  // brackets the traversal kernel only
@@ -1618,6 +1649,17 @@ int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)
 	}
 	h->traverse_waves = traverse_waves;
 	h->rerank_waves = rerank_waves;
+	return 1;
+}
+
+int mvdb_set_visited_mode(mvdb_index *h, int mode, int log_cap)
+{
+	if (mode < 0 || mode > 2 || log_cap < 0 || log_cap > (1 << 22)) {
+		h->set_error("mvdb_set_visited_mode: mode must be 0 (default), 1 (memset per launch) or 2 (log and clear), log_cap 0..4194304");
+		return 0;
+	}
+	h->visited_mode = mode;
+	h->visited_log_cap = log_cap;
 	return 1;
 }
 
