@@ -164,7 +164,7 @@ def test_scan_many_bit_exact(small):
 
 
 def test_scan_many_large_with_gaps(gpu):
-    """Large enough for the warm-start prefix sweep and the cross-split bound exchange (>= 65536 slots),
+    """Large enough for several levels of the level-wise sweep and the cross-split bound exchange (>= 65536 slots),
     with absent ids (gaps) and heavy value ties (coarse coordinates), k up to the kernel's maximum."""
     from minivectordb_amd import HipBridge
     n_slots, dim = 90000, 64
