@@ -455,6 +455,21 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                     pipeline_gbs=round((bytes_timed + rerank_bytes_timed) / elapsed / 1e9, 2))
 
     extras = {}
+    if not sharded:
+        # the same kernel with one batch at a time: what one launch achieves when it has the chip to itself
+        bridge._L.mvdb_enable_timing(bridge.handle, 1)
+        s.stage_stats(1)
+        k_solo = min(max(args.steps, 8), 2 * pl.nb)
+        for j in range(k_solo):
+            s.query_many(pl.q_dev[j % pl.nb], pl.ef_search, pl.ann_k)
+        torch.cuda.synchronize(dev)
+        n_solo, ms_solo = s.stage_stats(1)
+        bridge._L.mvdb_enable_timing(bridge.handle, 0)
+        if n_solo > 0 and ms_solo > 0:
+            solo_ms = ms_solo / n_solo
+            solo_bytes = sum(pl.b_ann[j % pl.nb] for j in range(k_solo)) / k_solo
+            roofline["solo_avg_launch_ms"] = round(solo_ms, 4)
+            roofline["solo_frac"] = round(solo_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     if world > 1 and sharded:  # the same ranks with no exchange: what "replicas" scaling would show
         el = pl.timed(args.steps, exchange=False)
         extras["replicas"] = dict(value=round(world * pl.nq / (el / args.steps), 2), unit="queries/s",
