@@ -599,7 +599,7 @@ def run_scan(args, torch, dist, dev, rank, world):
     exact = ids[:1000].cpu().numpy()
     hn_recall = recall_of(hi, exact, k)
     cpu = None
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import oracle as O
         ns = min(16, nq)
         ix = O.OracleIndex(dim, p["m"], p["ef_construction"], 8, seed=1)
