@@ -119,6 +119,14 @@ int mvdb_build_parallel(mvdb_index *h, const int8_t *packed, int n, int threads)
  * loads.  stats_out: NULL or 8 doubles {seconds, host-prefix seconds, distance evaluations, nodes expanded,
  * evictions, removed back edges, passes, nodes linked on the host}. */
 int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, double *stats_out);
+/* Bulk insert into a LIVE index with the same block-parallel builder: links ids element_count ..
+ * element_count + count - 1 (the batch form of insertManyPacked for fresh consecutive ids,
+ * src/core/wasm-bridge.ts:268-288 -> insert, assembly/hnsw.ts:719-834).  Needs dense ids (every id
+ * below element_count present, none above) and count ids of spare capacity; levels continue the
+ * RNG stream in id order as sequential inserts would, the edge order is block-parallel
+ * (mvdb_build_gpu's).  The device mirror is re-uploaded in full at the next search.  stats_out as
+ * mvdb_build_gpu.  Not to be called while host slots hold batches in flight. */
+int mvdb_append_gpu(mvdb_index *h, const int8_t *packed, int count, int max_block, double *stats_out);
 
 /* ---- float32 store (vectors.f32.bin, src/mini-vector-db.ts:1013-1036) ---- */
 /* Upload `rows` x dim f32 rows (row id at byte id*dim*4) for the rerank stage.

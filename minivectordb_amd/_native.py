@@ -49,6 +49,7 @@ SYMBOLS = [
     ("mvdb_update_vector", _i, [_vp, _i, _vp]),
     ("mvdb_build_parallel", _i, [_vp, _vp, _i, _i]),
     ("mvdb_build_gpu", _i, [_vp, _vp, _i, _i, _vp]),
+("mvdb_append_gpu", _i, [_vp, _vp, _i, _i, _vp]),
     ("mvdb_attach_f32", _i, [_vp, _vp, _i64, _i]),
     ("mvdb_prepare_queries", _i, [_vp, _vp, _i, _vp, _vp]),
     ("mvdb_prepare_queries_dev", _i, [_vp, _vp, _i, _vp, _vp, _vp]),

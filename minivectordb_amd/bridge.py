@@ -211,6 +211,17 @@ class HipBridge:
                 "host_linked")
         return dict(zip(keys, st.tolist()))
 
+    def appendGpu(self, packed, max_block: int = 0) -> dict:
+        """Bulk insert into the live index (mvdb_append_gpu): ids elementCount .. elementCount + n - 1, dense ids
+        required; the same block-parallel builder as buildGpu.  Returns the counters of the call."""
+        packed = self._rows(packed, np.int8, "appendGpu")
+        st = np.zeros(8, np.float64)
+        with self._lock:
+            self._check(self._L.mvdb_append_gpu(self.handle, _ptr(packed), packed.shape[0], int(max_block), _ptr(st)))
+        keys = ("seconds", "host_prefix_seconds", "n_dist", "n_expanded", "evictions", "removed_back_edges", "passes",
+                "host_linked")
+        return dict(zip(keys, st.tolist()))
+
     # ---- search ---------------------------------------------------------------
     def searchManyArrays(self, vectorsI8, k: int, with_counters: bool = False):
         q = self._rows(vectorsI8, np.int8, "searchMany")

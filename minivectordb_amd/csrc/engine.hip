@@ -735,27 +735,24 @@ extern "C" {
 // nodes linked per pass (<= 0: 32768).  stats_out (8 doubles, may be NULL): seconds total, seconds of the
 // sequential host prefix, distance evaluations, nodes expanded, evictions, reverse-edge removals, passes,
 // nodes linked on the host.
-int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, double *stats_out)
+// Links ids first .. first + count - 1 (dense ids, everything below `first` present) block by block on the GPU.
+// first == 0: a build from scratch (mvdb_build_gpu); first > 0: a bulk insert into the live index (mvdb_append_gpu).
+static int gpu_link_range(mvdb_index *h, const int8_t *packed, int first, int count, int max_block, double *stats_out)
 {
 	using clk = std::chrono::steady_clock;
-	if (h->g.element_count != 0) {
-		h->set_error("mvdb_build_gpu needs an empty index");
-		return 0;
-	}
-	if (!packed || n <= 0) return 1;
 	if (!ensure_device(h)) return 0;
 	HostGraph &g = h->g;
-	n = std::min(n, g.max_elements);
+	const int n = first + count;  // nodes once the call is done
 	const int dim = g.cfg.dim, m = g.cfg.m, m0 = g.cfg.m0();
 	if (m0 > kBuildMaxM0) {
-		h->set_error("mvdb_build_gpu: M_MAX0 > 64 is not supported (use mvdb_build_parallel)");
+		h->set_error("GPU builder: M_MAX0 > 64 is not supported (use mvdb_build_parallel / mvdb_insert_many)");
 		return 0;
 	}
 	if (max_block <= 0) max_block = 32768;
 	const auto t0 = clk::now();
-	const int linked0 = g.bulk_begin(packed, n, std::min(n, 2048));
+	const int linked0 = g.bulk_append_begin(packed, count, std::min(n, 2048));
 	const double prefix_s = std::chrono::duration<double>(clk::now() - t0).count();
-	double st[8] = {0, prefix_s, 0, 0, 0, 0, 0, (double)linked0};
+	double st[8] = {0, prefix_s, 0, 0, 0, 0, 0, (double)(linked0 - first)};
 	if (linked0 < n) {
 		h->dev.release();  // the search mirror is stale anyway; its memory is needed at 10 M+
 		int ef = g.cfg.ef_construction;
@@ -869,6 +866,38 @@ int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, do
 	st[0] = std::chrono::duration<double>(clk::now() - t0).count();
 	if (stats_out) std::memcpy(stats_out, st, sizeof(st));
 	return 1;
+}
+
+int mvdb_build_gpu(mvdb_index *h, const int8_t *packed, int n, int max_block, double *stats_out)
+{
+	if (h->g.element_count != 0) {
+		h->set_error("mvdb_build_gpu needs an empty index");
+		return 0;
+	}
+	if (!packed || n <= 0) return 1;
+	return gpu_link_range(h, packed, 0, std::min(n, h->g.max_elements), max_block, stats_out);
+}
+
+int mvdb_append_gpu(mvdb_index *h, const int8_t *packed, int count, int max_block, double *stats_out)
+{
+	HostGraph &g = h->g;
+	if (!packed || count <= 0) return 1;
+	const int first = g.element_count;
+	if (first + (long long)count > g.max_elements) {
+		h->set_error("mvdb_append_gpu: ids beyond the index capacity (max_elements)");
+		return 0;
+	}
+	for (int i = 0; i < g.max_elements; i++)
+		if (g.present(i) != (i < first)) {  // the builder addresses nodes by position: ids 0 .. element_count - 1, no gaps
+			h->set_error("mvdb_append_gpu needs dense ids (every id below element_count present, none above)");
+			return 0;
+		}
+	for (const auto &o : h->hs)
+		if (o.busy) {
+			h->set_error("mvdb_append_gpu: batches are in flight on the host slots; wait for them first");
+			return 0;
+		}
+	return gpu_link_range(h, packed, first, count, max_block, stats_out);
 }
 
 int mvdb_attach_f32(mvdb_index *h, const float *base, int64_t rows, int resident)

@@ -648,26 +648,39 @@ void HostGraph::update_and_reconnect(int id, const int8_t *v)
 
 int HostGraph::bulk_begin(const int8_t *packed, int n, int prefix)
 {
-	n = std::min(n, max_elements);
-	if (n <= 0) return 0;
+	return bulk_append_begin(packed, std::min(n, max_elements), prefix);
+}
+
+// ids element_count .. element_count + count - 1 (dense ids): vectors, levels (the RNG stream goes on in id order)
+// and empty lists; the first of them are linked here, sequentially, until `min_linked` nodes exist and the top
+// level is taken (a later node cannot raise the entry point then).  Returns the number of linked nodes.
+int HostGraph::bulk_append_begin(const int8_t *packed, int count, int min_linked)
+{
+	const int first = element_count;
+	count = std::min(count, max_elements - first);
+	if (count <= 0) return first;
+	const int n = first + count;
 	version++;
 	dirty_all = true;
-	std::memcpy(vec.data(), packed, (size_t)n * cfg.dim);
-	std::vector<int8_t> lv((size_t)n);
+	std::memcpy(vec.data() + (size_t)first * cfg.dim, packed, (size_t)count * cfg.dim);
+	std::vector<int8_t> lv((size_t)count);
 	size_t upper_total = 0;
-	for (int i = 0; i < n; i++) {
+	for (int i = 0; i < count; i++) {
 		lv[i] = (int8_t)random_level();
 		upper_total += (size_t)lv[i] * (1 + (size_t)cfg.m);
 	}
 	upper.reserve(upper.size() + upper_total);
-	for (int i = 0; i < n; i++) create_node(i, lv[i]);
-	entry_point = 0;
-	max_level = lv[0];
-	int k = 1;
-	for (; k < n && (k < prefix || max_level < kMaxLayers - 1); k++) {
-		link_new_node(k, lv[k], *main_, false, entry_point, max_level);
-		if (lv[k] > max_level) {  // insert :829-832
-			max_level = lv[k];
+	for (int i = 0; i < count; i++) create_node(first + i, lv[i]);
+	int k = first;
+	if (first == 0 || entry_point == -1 || !present(entry_point)) {
+		entry_point = first;
+		max_level = lv[0];
+		k = first + 1;
+	}
+	for (; k < n && (k < min_linked || max_level < kMaxLayers - 1); k++) {
+		link_new_node(k, lv[k - first], *main_, false, entry_point, max_level);
+		if (lv[k - first] > max_level) {  // insert :829-832
+			max_level = lv[k - first];
 			entry_point = k;
 		}
 	}

@@ -113,6 +113,7 @@ public:
 	// one with the reference algorithm, k >= prefix and large enough for max_level to have reached its
 	// cap (so that entry point and max_level are final).  Returns k.  bulk_end() publishes n nodes.
 	int bulk_begin(const int8_t *packed, int n, int prefix);
+	int bulk_append_begin(const int8_t *packed, int count, int min_linked);
 	void bulk_end(int n);
 
 private:

@@ -51,6 +51,7 @@ class MiniVectorDB:
             baseEfSearch=preset["baseEfSearch"], rerankMultiplier=preset["rerankMultiplier"],
             maxAnnK=preset["maxAnnK"], resultsCap=preset["resultsCap"],
             preloadVectors=bool(o.get("preloadVectors", False)), seed=o.get("seed"),
+            bulkInsert=o.get("bulkInsert"), bulkInsertMin=int(o.get("bulkInsertMin") or 4096),  # engine options
         )
         p = lambda name: os.path.join(self.storageDir, self.prefix + name)  # :146-150
         self.dumpPath, self.vecPath, self.oplogPath = p("dump.bin"), p("vectors.f32.bin"), p("ann.oplog")
@@ -170,7 +171,19 @@ class MiniVectorDB:
             for iid, row in zip(ids, qn):
                 f.seek(iid * dim * 4)
                 f.write(row.astype("<f4").tobytes())
-        self.wasm.insertManyPacked(np.asarray(ids, np.int32), q8.reshape(-1), dim)       # :356
+        ids_a = np.asarray(ids, np.int32)
+        first = self.wasm.elementCount()
+        # engine option (not in the reference): a large batch of fresh consecutive ids goes through the GPU builder
+        # (mvdb_append_gpu: same per-insert algorithm, block-parallel edge order) instead of one insert at a time
+        bulk = (self.cfg.get("bulkInsert") == "gpu" and len(ids) >= int(self.cfg.get("bulkInsertMin", 4096))
+                and np.array_equal(ids_a, np.arange(first, first + len(ids), dtype=np.int32)))
+        if bulk:
+            try:
+                self.wasm.appendGpu(q8)
+            except MvdbError:                                     # ids not dense (holes below): the ordinary path
+                bulk = False
+        if not bulk:
+            self.wasm.insertManyPacked(ids_a, q8.reshape(-1), dim)                       # :356
         with open(self.oplogPath, "a") as f:                      # :358-361
             f.write("".join(f"U {i}\n" for i in ids))
 

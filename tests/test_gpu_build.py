@@ -126,3 +126,95 @@ def test_gpu_build_is_deterministic(gpu):
         dumps.append(b.saveBytes())
         b.close()
     assert dumps[0] == dumps[1]
+
+
+def test_gpu_append_into_a_live_index(gpu):
+    """mvdb_append_gpu: a bulk insert of fresh consecutive ids into an index that is being searched.  Levels and rows
+    equal those of one build over all the data (the RNG stream goes on in id order), the dump is a valid V3 file,
+    searches after the append are bit-exact against the oracle on that dump, quality matches a single build, and
+    the misuse cases are errors."""
+    from minivectordb_amd import HipBridge, MvdbError
+    n0, n1, dim, preset = 30000, 12000, 64, "balanced"
+    p = O.PRESETS[preset]
+    rng = np.random.default_rng(7)
+    base = O.normalize_rows_f32(rng.standard_normal((n0 + n1, dim), dtype=np.float32))
+    b8 = O.quantize_rows_i8(base)
+    cfg = dict(dim=dim, m=p["m"], ef=p["ef_construction"], capacity=n0 + n1, seed=42, resultsCap=4096)
+    whole = HipBridge()
+    whole.init(cfg)
+    whole.buildGpu(b8)
+    b = HipBridge()
+    b.init(cfg)
+    b.buildGpu(b8[:n0])
+    q = gaussian_unit(300, dim, 99)
+    q8 = O.quantize_rows_i8(q)
+    b.setEfSearch(p["baseEfSearch"])
+    before = b.searchManyArrays(q8, 100)                         # the index is live: device mirror uploaded
+    assert before[0].max() < n0
+    st = b.appendGpu(b8[n0:])
+    assert b.elementCount() == n0 + n1 and st["passes"] >= 1 and st["n_dist"] > 0
+    dump = b.saveBytes()
+    ix = O.OracleIndex(dim, p["m"], p["ef_construction"], 8, seed=1)
+    assert ix.load_bytes(dump) and ix.save_bytes() == dump
+    recs, ref = D.walk(dump), D.walk(whole.saveBytes())
+    assert [(r[0], r[1]) for r in recs] == [(r[0], r[1]) for r in ref]      # same ids, same levels as one build
+    for nid, lvl, vec_off, lists in recs[::997]:
+        assert dump[vec_off:vec_off + dim] == b8[nid].tobytes()
+    # bit-exact search on the appended index, new nodes are found
+    ix.set_ef_search(p["baseEfSearch"]); ix.set_results_cap(4096)
+    ids, dist, cnt, ctr = b.searchManyArrays(q8, 100, with_counters=True)
+    oi, od, oc, octr = ix.search_many(q8, 100, threads=8)
+    assert np.array_equal(cnt, oc) and np.array_equal(ids, oi) and np.array_equal(dist.view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(ctr[:, 0], octr["n_dist"])
+    assert (ids >= n0).any()
+    self_q = b.searchManyArrays(b8[n0 + 5:n0 + 6], 1)
+    assert self_q[0][0, 0] == n0 + 5 and self_q[1][0, 0] == 0.0
+    # quality: recall against the exact answer as good as one build over everything
+    gt = _exact_topk(base, O.normalize_rows_f32(q))
+    whole.setEfSearch(p["baseEfSearch"])
+    r_app, r_whole = _recall(ids, gt), _recall(whole.searchManyArrays(q8, 100)[0], gt)
+    assert r_app >= r_whole - 0.02, (r_app, r_whole)
+    # misuse
+    with pytest.raises(MvdbError, match="capacity"):
+        b.appendGpu(b8[:10])
+    holes = HipBridge()
+    holes.init(cfg)
+    holes.insertManyPacked(np.array([0, 1, 3], np.int32), b8[:3], dim)
+    with pytest.raises(MvdbError, match="dense"):
+        holes.appendGpu(b8[:10])
+    # an append into an EMPTY index is a build; a small append stays on the host prefix path
+    e = HipBridge()
+    e.init(cfg)
+    e.appendGpu(b8[:500])
+    e.appendGpu(b8[500:1500])
+    assert e.elementCount() == 1500
+    ix2 = O.OracleIndex(dim, p["m"], p["ef_construction"], 8, seed=1)
+    assert ix2.load_bytes(e.saveBytes())
+    for x in (whole, b, holes, e):
+        x.close()
+
+
+def test_db_facade_bulk_insert_option(gpu):
+    """MiniVectorDB.insertMany with the engine option bulkInsert="gpu": large batches of fresh ids go through
+    mvdb_append_gpu, small ones and upserts through insert; search, save and re-open work as with the ordinary path."""
+    import tempfile
+    from minivectordb_amd.db import MiniVectorDB
+    dim, n = 64, 9000
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        db = MiniVectorDB.open(dict(storageDir=d, dim=dim, mode="fast", capacity=20000, preloadVectors=True,
+                                    bulkInsert="gpu", bulkInsertMin=2000))
+        db.insertMany([dict(id=f"a-{i}", input=x[i], metadata=dict(i=i)) for i in range(100)])        # small: host path
+        db.insertMany([dict(id=f"a-{i}", input=x[i], metadata=dict(i=i)) for i in range(100, 6000)])  # bulk: GPU
+        assert db.wasm.uploadCounters()["full_uploads"] >= 0
+        db.insertMany([dict(id=f"a-{i}", input=x[i], metadata=dict(i=i)) for i in range(5990, n)])    # upserts + new: host
+        res = db.searchMany([x[5], x[3000], x[8999]], dict(topK=3))
+        assert [r[0]["id"] for r in res] == ["a-5", "a-3000", "a-8999"]
+        assert all(abs(r[0]["score"]) < 1e-6 for r in res)
+        db.save()
+        db.close()
+        db2 = MiniVectorDB.open(dict(storageDir=d, dim=dim, mode="fast", capacity=20000, preloadVectors=True))
+        res2 = db2.searchMany([x[5], x[3000], x[8999]], dict(topK=3))
+        assert res2 == res
+        db2.close()
