@@ -101,6 +101,10 @@ class HipBridge {
 		}
 		await this.withLock(() => { native.insertManyPacked(this.h, ids, packed); });
 	}
+	// Engine extensions (no WasmBridge counterpart): block-parallel linking on the GPU, same per-insert algorithm.
+	// buildGpu: ids 0..n-1 into an empty index; appendGpu: ids elementCount.. into the live index (dense ids).
+	async buildGpu(packed) { return this.withLock(() => native.bulkLink(this.h, packed, 0)); }
+	async appendGpu(packed) { return this.withLock(() => native.bulkLink(this.h, packed, 1)); }
 	async updateVector(id, vectorI8) { // :290 update_and_reconnect: an absent id is a silent no-op
 		await this.withLock(() => {
 			if (native.hasNode(this.h, id | 0)) native.insertManyPacked(this.h, Int32Array.of(id), this._vec(vectorI8, "updateVector"));

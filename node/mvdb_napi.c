@@ -185,6 +185,26 @@ static napi_value InsertManyPacked(napi_env env, napi_callback_info info)
 	if (!mvdb_insert_many(h, ids, vec, (int)(nb_ids / 4))) return throw_last(env, h);
 	return NULL;
 }
+/* bulkLink(h, Int8Array packed, append) -> seconds: mvdb_build_gpu (append = 0: ids 0..n-1 into an empty index) or
+ * mvdb_append_gpu (append = 1: ids elementCount.. into the live index); n = packed.length / dim */
+static napi_value BulkLink(napi_env env, napi_callback_info info)
+{
+	size_t argc = 3, nb;
+	napi_value a[3], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, a, NULL, NULL));
+	mvdb_index *h = get_handle(env, a[0]);
+	if (!h) return NULL;
+	const int8_t *vec = (const int8_t *)bytes_of(env, a[1], &nb);
+	const int append = get_i32(env, a[2]);
+	const size_t dim = (size_t)mvdb_get_dim(h);
+	if (!vec || dim == 0 || nb % dim != 0 || nb / dim > 0x7fffffff)
+		return throw_type(env, "bulkLink: packed must be an Int8Array of n * dim values");
+	double st[8] = {0};
+	const int n = (int)(nb / dim);
+	if (!(append ? mvdb_append_gpu(h, vec, n, 0, st) : mvdb_build_gpu(h, vec, n, 0, st))) return throw_last(env, h);
+	NAPI_OK(napi_create_double(env, st[0], &out));
+	return out;
+}
 /* loadDump(h, Buffer) -> boolean (false = load_index returned 0; the index is fresh and empty) */
 static napi_value LoadDump(napi_env env, napi_callback_info info)
 {
@@ -376,7 +396,7 @@ static napi_value Init(napi_env env, napi_value exports)
 	           {"insertManyPacked", InsertManyPacked}, {"loadDump", LoadDump}, {"saveDump", SaveDump},
 	           {"searchMany", SearchMany}, {"attachF32", AttachF32}, {"queryMany", QueryMany},
 	           {"prepareQueries", PrepareQueries}, {"deviceAvailable", DeviceAvailable}, {"submitMany", SubmitMany},
-	           {"waitMany", WaitMany}};
+	           {"waitMany", WaitMany}, {"bulkLink", BulkLink}};
 	for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {
 		napi_value f;
 		if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

@@ -75,6 +75,19 @@ function oneHotI8(dim, i) { const v = new Int8Array(dim); v[i % dim] = 127; retu
 	assert(badBatch.length > 0, "a ragged batch must throw");
 	const after = await b.queryManyBatches([batches[1]], 5, 140, 360); // no slot was left busy by the failed sweep
 	assert(after.length === 1 && after[0].n.length === batches[1].length / dim, "slots are free again after an error");
+	// GPU bulk build + bulk append through the addon: every stored vector finds itself
+	const bb = new HipBridge();
+	await bb.init({ dim: 64, m: 16, ef: 200, efSearch: 64, capacity: 6000, seed: 7, resultsCap: 4096 });
+	const pk = new Int8Array(5000 * 64);
+	let sd = 12345;
+	for (let i = 0; i < pk.length; i++) { sd = (sd * 1103515245 + 12345) & 0x7fffffff; pk[i] = (sd >> 16) % 255 - 127; }
+	await bb.buildGpu(pk.subarray(0, 4000 * 64));
+	await bb.appendGpu(pk.subarray(4000 * 64));
+	assert((await bb.searchMany([pk.subarray(10 * 64, 11 * 64), pk.subarray(4500 * 64, 4501 * 64)], 1)).map((r) => r[0].id).join() === "10,4500", "bulk-linked vectors find themselves");
+	let noRoom = "";
+	try { await bb.appendGpu(pk.subarray(0, 2000 * 64)); } catch (e) { noRoom = String(e.message); }
+	assert(/capacity/.test(noRoom), "appendGpu beyond the capacity must throw");
+	bb.close();
 	b.close(); b2.close(); b3.close();
 	console.log("node bridge test passed");
 })().catch((e) => { console.error("FAILED:", e); process.exit(1); });
