@@ -1418,14 +1418,14 @@ int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, 
 		if (s.pin_in) HIP_OK(h, hipHostFree(s.pin_in));
 		s.pin_in = nullptr;
 		s.pin_in_cap = 0;
-		HIP_OK(h, hipHostMalloc(&s.pin_in, in_bytes, hipHostMallocDefault));
+		HIP_OK(h, hipHostMalloc(&s.pin_in, in_bytes, hipHostMallocMapped));
 		s.pin_in_cap = in_bytes;
 	}
 	if (s.pin_out_cap < out_bytes) {
 		if (s.pin_out) HIP_OK(h, hipHostFree(s.pin_out));
 		s.pin_out = nullptr;
 		s.pin_out_cap = 0;
-		HIP_OK(h, hipHostMalloc(&s.pin_out, out_bytes, hipHostMallocDefault));
+		HIP_OK(h, hipHostMalloc(&s.pin_out, out_bytes, hipHostMallocMapped));
 		s.pin_out_cap = out_bytes;
 	}
 	s.nq = nq;
@@ -1434,15 +1434,18 @@ int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, 
 		s.busy = true;
 		return 1;
 	}
-	float *d_in = static_cast<float *>(s.d_in.need(nqd * 4));
-	int32_t *d_oi = static_cast<int32_t *>(s.d_ids.need((size_t)nq * tk * 4));
-	double *d_ol = static_cast<double *>(s.d_l2.need((size_t)nq * tk * 8));
-	int32_t *d_on = static_cast<int32_t *>(s.d_n.need((size_t)nq * 4));
+	// Zero-copy: the prep kernel reads the queries from the pinned (device-mapped) staging buffer and the rerank
+	// kernel writes the results into the pinned output block -- 1.5 MB in, 0.12 MB out per 1 k-query batch over the
+	// host link inside the kernels, instead of three DMA operations (and their latencies) around them.
+	void *d_in_v = nullptr, *d_out_v = nullptr;
+	HIP_OK(h, hipHostGetDevicePointer(&d_in_v, s.pin_in, 0));
+	HIP_OK(h, hipHostGetDevicePointer(&d_out_v, s.pin_out, 0));
+	unsigned char *po = static_cast<unsigned char *>(d_out_v);
+	float *d_in = static_cast<float *>(d_in_v);
+	double *d_ol = reinterpret_cast<double *>(po);
+	int32_t *d_oi = reinterpret_cast<int32_t *>(po + (size_t)nq * tk * 8);
+	int32_t *d_on = reinterpret_cast<int32_t *>(po + (size_t)nq * tk * 12);
 	uint32_t *d_allow = nullptr;
-	if (!d_in || !d_oi || !d_ol || !d_on) {
-		h->set_error("out of device memory (query slot staging)");
-		return 0;
-	}
 	if (allow) {
 		const size_t words = ((size_t)std::max<int64_t>(h->g.max_elements, 1) + 31) / 32;
 		d_allow = static_cast<uint32_t *>(s.d_allow.need(words * 4));
@@ -1454,12 +1457,7 @@ int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, 
 		HIP_OK(h, hipMemcpyAsync(d_allow, allow, words * 4, hipMemcpyHostToDevice, s.stream));
 	}
 	std::memcpy(s.pin_in, q_f32, nqd * 4);
-	HIP_OK(h, hipMemcpyAsync(d_in, s.pin_in, nqd * 4, hipMemcpyHostToDevice, s.stream));
 	if (!mvdb_query_many_dev(h, d_in, nq, topk, ef_search, ann_k, d_allow, d_oi, d_ol, d_on, nullptr, s.stream)) return 0;
-	unsigned char *po = static_cast<unsigned char *>(s.pin_out);
-	HIP_OK(h, hipMemcpyAsync(po, d_ol, (size_t)nq * tk * 8, hipMemcpyDeviceToHost, s.stream));
-	HIP_OK(h, hipMemcpyAsync(po + (size_t)nq * tk * 8, d_oi, (size_t)nq * tk * 4, hipMemcpyDeviceToHost, s.stream));
-	HIP_OK(h, hipMemcpyAsync(po + (size_t)nq * tk * 12, d_on, (size_t)nq * 4, hipMemcpyDeviceToHost, s.stream));
 	s.busy = true;
 	return 1;
 }
