@@ -1544,18 +1544,20 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.nq = nq;
 	a.k = k;
 	a.metric = metric;
-	a.qtiles = (nq + kScanQB - 1) / kScanQB;
-	a.s2 = scan_s2_for(nq);
-	a.nsplit = 8 * a.s2;
+	a.wide = (k <= kWideMaxK && nq >= kScanWideMinQ) ? kWideMinLevel : 0;
 	a.nodes_per_split = 0;
 	a.level0 = kScanLevel0;
 	a.level_ratio = kScanLevelRatio;
 #ifdef MVDB_SCAN_TUNE  // experiments only (tools/scan_bench.py); the shipped library has no such knob
+	if (const char *e = getenv("MVDB_SCAN_WIDE")) a.wide = k <= kWideMaxK ? std::max(0, atoi(e)) : 0;  // 1: every level
 	if (const char *e = getenv("MVDB_SCAN_LEVEL0")) a.level0 = std::max(64, atoi(e) / 64 * 64);
 	if (const char *e = getenv("MVDB_SCAN_RATIO")) a.level_ratio = std::max(2, atoi(e));
 #endif
-	int level_ends[kScanMaxLevels];
-	a.nslots = scan_levels(N, level_ends, a.level0, a.level_ratio) * a.nsplit;
+	a.qtiles = a.s2 = a.nsplit = 0;  // per level (scan_plan)
+	{
+		ScanLevel plan[kScanMaxLevels];
+		scan_plan(N, nq, a.wide, a.level0, a.level_ratio, plan, &a.nslots);
+	}
 	const size_t part_elems = (size_t)nq * a.nslots * k;
 	const size_t part_bytes = part_elems * 8 + (((size_t)nq * a.nslots * 4 + 7) & ~(size_t)7);
 	unsigned char *part = static_cast<unsigned char *>(h->scan_part.need(part_bytes + (size_t)nq * 8));

@@ -47,11 +47,12 @@ struct ScanArgs {
 	const int32_t *norm2;  // |v|^2 per node, -1 = absent
 	const int8_t *q;
 	int nq, k, metric;
-	int qtiles, s2, nsplit;  // nsplit = 8 * s2
+	int qtiles, s2, nsplit;  // nsplit = 8 * s2 (per level, set by the launcher)
 	int nodes_per_split;     // multiple of kScanStage (per level, set by the launcher)
 	int node_lo, node_hi;    // node range of this level
 	int slot0, nslots;       // partial-list slot of split 0 of this level; slots per query over all levels
 	int level0, level_ratio; // level plan (scan_levels)
+	int wide;                // > 0: levels of at least this many nodes go to scan_wide_kernel (k <= kWideMaxK); see scan_plan
 	unsigned long long *thr_g;     // [nq] smallest k-th key published by any split, ~0 before the launch
 	unsigned long long *dbg;       // MVDB_SCAN_DEBUG builds: 8 counters (see tools/scan_debug.py)
 	unsigned long long *part_key;  // [nq][nslots][k]
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 	compact_rows((unsigned)__ballot(owner && cnt[lane & (kScanWR - 1)] > 0));  // every row: best min(n, k), sorted
 #ifdef MVDB_SCAN_DEBUG
 	dbg_c[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
-	if (lane == 0 && a.dbg)
+	if (lane == 0 && a.dbg && !a.wide)  // (a sweep that uses the wide kernel reports that kernel's counters)
 		for (int i = 0; i < 16; i++) atomicAdd(&a.dbg[i], dbg_c[i]);
 #endif
 
@@ -765,48 +766,106 @@ constexpr int kScanLevel0 = 1024;   // nodes of the first level (no bound yet)
 constexpr int kScanLevelRatio = 8;  // each later level ends at ratio x its start
 constexpr int kScanMaxLevels = 16;
 
-// ends[i] = end of level i (multiples of kScanStage, last = N); returns the number of levels
-__host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 = kScanLevel0, int ratio = kScanLevelRatio)
+// ends[i] = end of level i (multiples of kScanStage, last = N); returns the number of levels.
+// fine_from > 0: where the next level at `ratio` would hold at least that many nodes, levels only double -- the
+// wide kernel takes those, pays more per candidate than scan_kernel, and a doubling level brings ~k candidates
+// per query instead of ~k (ratio - 1).
+__host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 = kScanLevel0, int ratio = kScanLevelRatio, int fine_from = 0)
 {
 	int n = 0;
 	long long e = level0;
 	while (e < N && n < kScanMaxLevels - 1) {
 		ends[n++] = (int)e;
-		e *= ratio;
+		e *= (fine_from > 0 && e * (ratio - 1) >= fine_from) ? 2 : ratio;
 	}
 	ends[n++] = N;
 	return n;
 }
 
+}  // namespace mvdb
+#include "scan_wide.hip.hpp"
+namespace mvdb {
+
+}  // namespace mvdb
+#include "scan_wide.hip.hpp"
+namespace mvdb {
+
+// The plan of one sweep: per level its node range, which kernel takes it, its node splits and first list slot.
+// Levels of at least a.wide nodes (kWideMinLevel when the engine turns it on) go to scan_wide_kernel; the small
+// first levels, where almost every element is a candidate, stay with scan_kernel (its candidate path is overlapped
+// by the partner wave, the wide kernel's is not).
+struct ScanLevel {
+	int lo, hi, wide, qtiles, s2, nsplit, slot0;
+};
+constexpr int kWideMinLevel = 100000;
+
+__host__ inline int scan_plan(int N, int nq, int wide, int level0, int ratio, ScanLevel (&lv)[kScanMaxLevels], int *total_slots)
+{
+	int ends[kScanMaxLevels];
+	const int levels = scan_levels(N, ends, level0, ratio, wide);
+	int lo = 0, slot = 0;
+	for (int l = 0; l < levels; l++) {
+		ScanLevel &v = lv[l];
+		v.lo = lo;
+		v.hi = ends[l];
+		v.wide = (wide > 0 && v.hi - v.lo >= wide) ? 1 : 0;
+		v.qtiles = v.wide ? (nq + kWideQB - 1) / kWideQB : (nq + kScanQB - 1) / kScanQB;
+		v.s2 = v.wide ? scan_wide_s2_for(nq) : scan_s2_for(nq);
+		v.nsplit = 8 * v.s2;
+		v.slot0 = slot;
+		slot += v.nsplit;
+		lo = ends[l];
+	}
+	*total_slots = slot;
+	return levels;
+}
+
+// one sweep = the levels in turn, each followed by the merge that turns its lists into the next level's bounds
 template <int KS, int METRIC, int CAP>
 inline bool launch_scan_t(const ScanArgs &a0, hipStream_t s)
 {
-	const size_t lds = scan_lds_bytes<KS, CAP, scan_buffers<KS, CAP>()>();
+	constexpr bool HAS_WIDE = CAP == kScanCapSmall;  // a.wide implies k <= kWideMaxK <= kScanSmallK
+	constexpr size_t lds_std = scan_lds_bytes<KS, CAP, scan_buffers<KS, CAP>()>();
+	constexpr int WKS = KS == 6 ? 8 : KS;  // no 6-step wide kernel (the compiler does not unroll it): rows of 257..384 bytes take the 8-step one
+	constexpr size_t lds_wide = scan_wide_lds_bytes<WKS>();
 	static bool attr_set[16] = {};  // per device, once
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
 	if (!attr_set[dev]) {
-		if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KS, METRIC, CAP>),
-		                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KS, METRIC, CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                        (int)lds_std) != hipSuccess)
 			return false;
+		if constexpr (HAS_WIDE) {
+			if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_wide_kernel<WKS, METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+			                        (int)lds_wide) != hipSuccess)
+				return false;
+		}
 		attr_set[dev] = true;
 	}
-	int ends[kScanMaxLevels];
-	const int levels = scan_levels(a0.ix.max_elements, ends, a0.level0, a0.level_ratio);
-	if (levels * a0.nsplit > a0.nslots) return false;
+	if (a0.wide && (!HAS_WIDE || a0.k > kWideMaxK)) return false;
+	ScanLevel lv[kScanMaxLevels];
+	int total = 0;
+	const int levels = scan_plan(a0.ix.max_elements, a0.nq, a0.wide, a0.level0, a0.level_ratio, lv, &total);
+	if (total > a0.nslots) return false;
 	ScanArgs a = a0;
-	int lo = 0;
 	for (int l = 0; l < levels; l++) {
-		a.node_lo = lo;
-		a.node_hi = ends[l];
-		a.slot0 = l * a.nsplit;
+		a.node_lo = lv[l].lo;
+		a.node_hi = lv[l].hi;
+		a.qtiles = lv[l].qtiles;
+		a.s2 = lv[l].s2;
+		a.nsplit = lv[l].nsplit;
+		a.slot0 = lv[l].slot0;
 		a.nodes_per_split = (((a.node_hi - a.node_lo + a.nsplit - 1) / a.nsplit) + kScanStage - 1) / kScanStage * kScanStage;
-		hipLaunchKernelGGL((scan_kernel<KS, METRIC, CAP>), dim3(a.qtiles * a.nsplit), dim3(kScanThreads), lds, s, a);
+		if (lv[l].wide) {
+			if constexpr (HAS_WIDE)
+				hipLaunchKernelGGL((scan_wide_kernel<WKS, METRIC>), dim3(a.qtiles * a.nsplit), dim3(256), lds_wide, s, a);
+		} else {
+			hipLaunchKernelGGL((scan_kernel<KS, METRIC, CAP>), dim3(a.qtiles * a.nsplit), dim3(kScanThreads), lds_std, s, a);
+		}
 		if (l + 1 < levels)
-			hipLaunchKernelGGL(scan_merge_kernel<false>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a, (l + 1) * a.nsplit);
-		lo = ends[l];
+			hipLaunchKernelGGL(scan_merge_kernel<false>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a, lv[l].slot0 + lv[l].nsplit);
 	}
-	hipLaunchKernelGGL(scan_merge_kernel<true>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a, levels * a.nsplit);
+	hipLaunchKernelGGL(scan_merge_kernel<true>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a, total);
 	return hipGetLastError() == hipSuccess;
 }
 

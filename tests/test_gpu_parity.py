@@ -232,3 +232,52 @@ def test_scan_many_partial_rows(gpu, dim, n):
             assert np.array_equal(gc, oc)
             assert np.array_equal(gi, oi), (metric, k)
             assert np.array_equal(gv, ov), (metric, k)
+
+
+def _exact_topk(b8, q8, k, metric):
+    """Exhaustive top-k in numpy with the scan's order: ascending L2 (or descending dot), ties to the lower id.
+    float32 GEMM is exact here: every partial sum is an integer below 2^24 (|dot| <= 127^2 * 512 < 2^24)."""
+    n = b8.shape[0]
+    vf = b8.astype(np.float32)
+    vn = (b8.astype(np.int64) ** 2).sum(1)
+    ids = np.empty((q8.shape[0], k), np.int32)
+    vals = np.empty((q8.shape[0], k), np.int32)
+    for s in range(0, q8.shape[0], 256):
+        qc = q8[s:s + 256]
+        dot = (qc.astype(np.float32) @ vf.T).astype(np.int64)
+        val = (qc.astype(np.int64) ** 2).sum(1)[:, None] + vn[None, :] - 2 * dot if metric == "l2" else -dot
+        key = (val << 20) | np.arange(n, dtype=np.int64)[None, :]          # n < 2^20
+        part = np.argpartition(key, k - 1, axis=1)[:, :k]
+        kk = np.take_along_axis(key, part, 1)
+        order = np.argsort(kk, axis=1)
+        top = np.take_along_axis(part, order, 1)
+        ids[s:s + 256] = top
+        v = np.take_along_axis(val, top, 1)
+        vals[s:s + 256] = v if metric == "l2" else -v
+    return ids, vals
+
+
+@pytest.mark.parametrize("dim,rows,slots,nq,k,metric,coarse", [(64, 235000, 240000, 3100, 10, "l2", True),
+                                                                (320, 236000, 236000, 3072, 12, "dot", False),
+                                                                (512, 240000, 240000, 3073, 1, "l2", False)])
+def test_scan_many_wide_levels(gpu, dim, rows, slots, nq, k, metric, coarse):
+    """Batches of >= 3072 queries with k <= 12 send every level of >= 100 000 nodes to the wide scan kernel (512
+    queries per workgroup, A fragments in AccVGPRs): 2-, 8-(for a 6-step row) and 8-k-step instantiations, a ragged
+    last query tile, absent slots behind the last row, value ties.  Checked against an exhaustive numpy top-k."""
+    from minivectordb_amd import HipBridge
+    rng = np.random.default_rng(dim + k)
+    if coarse:
+        b8 = (rng.integers(-3, 4, (rows, dim)) * 40).astype(np.int8)
+        q8 = (rng.integers(-3, 4, (nq, dim)) * 40).astype(np.int8)
+    else:
+        b8 = rng.integers(-127, 128, (rows, dim), dtype=np.int16).astype(np.int8)
+        q8 = rng.integers(-127, 128, (nq, dim), dtype=np.int16).astype(np.int8)
+    b = HipBridge()
+    b.init(dict(dim=dim, m=2, ef=4, capacity=slots, seed=3))
+    b.buildParallel(b8, 16)
+    gi, gv, gc = b.scanMany(q8, k, metric)
+    oi, ov = _exact_topk(b8, q8, k, metric)
+    assert np.all(gc == k)
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gv, ov)
+    b.close()
