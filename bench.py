@@ -647,7 +647,7 @@ def run_scan(args, torch, dist, dev, rank, world):
                    dtype="i8", data="synthetic",
                    config=dict(workload=f"{n}x{dim} exact int8 brute-force scan, batch {nq} queries, top-{k}", n=n, dim=dim,
                                nq=nq, topk=k, mode="single" if world == 1 else "replicas", build=st),
-                   roofline=dict(bound="mfma", kernel="scan_kernel", achieved=round(ops / (scan_ms * 1e-3) / 1e12, 2),
+                   roofline=dict(bound="mfma", kernel="whole sweep: scan_kernel (small levels) + scan_wide_kernel (levels >= 100k nodes) + merges", achieved=round(ops / (scan_ms * 1e-3) / 1e12, 2),
                                  peak=I8_MFMA_PEAK_TOPS, unit="TOP/s (int8 multiply-add = 2 ops)",
                                  frac=round(ops / (scan_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, 5), traffic=None,
                                  ops_per_launch=ops, avg_launch_ms=round(scan_ms, 4)),

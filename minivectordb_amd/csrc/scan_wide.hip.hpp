@@ -1,21 +1,22 @@
-// scan_wide.hip.hpp -- the exact scan's kernel for small k (k <= kWideMaxK), included by scan_mfma.hip.hpp.
+// scan_wide.hip.hpp -- the exact scan's kernel for the large levels of big batches (k <= kWideMaxK, see scan_plan),
+// included by scan_mfma.hip.hpp.
 //
 // Same algorithm, bounds, levels, LDS tile image and LDS-DMA fill as scan_kernel (see there), other shape:
-// ONE wave per SIMD that keeps 128 queries as A fragments (256 registers at 512-d; the kernel may use the whole
+// ONE wave per SIMD that keeps 128 queries as A fragments (256 registers at 512-d: the AccVGPR half of the
 // 512-register file), 512 queries per workgroup.  Why: filling LDS costs the CU ~1300 cycles per 64-row tile
 // whichever way it is done (the vector-memory return path moves ~30 B/clk per CU), and the MFMA work a staged
 // byte is good for is set by the number of queries the CU holds.  256 queries (scan_kernel: 2 waves x 32
 // queries per SIMD, the most that fits in 256 registers next to the rest) make a tile 2048 matrix-pipe cycles,
-// 512 queries make it 4096, a B fragment read from LDS feeds 8 MFMAs instead of 2, and there are half as many
-// tiles, barriers and DMA instructions per query.  What the two-wave shape bought -- a partner wave that keeps
-// the matrix pipe busy while one handles candidates -- matters little since the level-wise sweep cut the
-// candidates to ~0.1 entries per 32 x 32 elements.  Row buffers hold 16 keys (k <= 12), two tile buffers.
+// 512 queries make it 4096, and there are half as many tiles, barriers and DMA instructions per query.  What the
+// two-wave shape bought -- a partner wave that keeps the matrix pipe busy while one handles candidates or
+// issues VALU instructions -- has to be made up by hand here: nothing is hidden with one wave per SIMD
+// (DESIGN.md 4.3 has the measurements behind each choice below).  Row buffers hold 16 keys, two tile buffers.
 #pragma once
 #include <climits>
 #include <type_traits>
 
 #ifndef MVDB_WIDE_ABLATE
-#define MVDB_WIDE_ABLATE 0  // experiments: 1 no slow path, 2 no candidate test, 8 no tile fill after the first
+#define MVDB_WIDE_ABLATE 0  // experiments (timing only, wrong results): 1 no candidate path, 2 no candidate test, 8 no tile fill after the first
 #endif
 
 namespace mvdb {

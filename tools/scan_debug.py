@@ -1,12 +1,16 @@
 """Diagnostic: where the scan kernel's wave time goes (MVDB_SCAN_DEBUG variant library, never shipped).
 
-    python tools/build_variants.py scandbg:MVDB_SCAN_DEBUG && MVDB_HIP_LIB=.../libmvdb_hip_scandbg.so python tools/scan_debug.py
+    python tools/build_variants.py scandbg:MVDB_SCAN_DEBUG,MVDB_SCAN_TUNE && MVDB_HIP_LIB=.../libmvdb_hip_scandbg.so python tools/scan_debug.py
+
+(scan_kernel on every level: MVDB_SCAN_WIDE=0, a knob of MVDB_SCAN_TUNE builds; tools/scan_wide_debug.py is the wide kernel's.)
 """
 import ctypes as C
 import os
 import sys
 
 import numpy as np
+
+os.environ["MVDB_SCAN_WIDE"] = "0"
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from minivectordb_amd import HipBridge  # noqa: E402
