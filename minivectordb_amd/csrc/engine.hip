@@ -1545,10 +1545,12 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.k = k;
 	a.metric = metric;
 	a.wide = (k <= kWideMaxK && nq >= kScanWideMinQ) ? kWideMinLevel : 0;
+	a.seed = 1;
 	a.nodes_per_split = 0;
 	a.level0 = kScanLevel0;
 	a.level_ratio = kScanLevelRatio;
 #ifdef MVDB_SCAN_TUNE  // experiments only (tools/scan_bench.py); the shipped library has no such knob
+	if (const char *e = getenv("MVDB_SCAN_SEED")) a.seed = atoi(e) != 0 ? 1 : 0;
 	if (const char *e = getenv("MVDB_SCAN_WIDE")) a.wide = k <= kWideMaxK ? std::max(0, atoi(e)) : 0;  // 1: every level
 	if (const char *e = getenv("MVDB_SCAN_LEVEL0")) a.level0 = std::max(64, atoi(e) / 64 * 64);
 	if (const char *e = getenv("MVDB_SCAN_RATIO")) a.level_ratio = std::max(2, atoi(e));
@@ -1556,7 +1558,7 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.qtiles = a.s2 = a.nsplit = 0;  // per level (scan_plan)
 	{
 		ScanLevel plan[kScanMaxLevels];
-		scan_plan(N, nq, a.wide, a.level0, a.level_ratio, plan, &a.nslots);
+		scan_plan(N, nq, a.wide, a.seed, a.level0, a.level_ratio, plan, &a.nslots);
 	}
 	const size_t part_elems = (size_t)nq * a.nslots * k;
 	const size_t part_bytes = part_elems * 8 + (((size_t)nq * a.nslots * 4 + 7) & ~(size_t)7);

@@ -52,6 +52,7 @@ struct ScanArgs {
 	int node_lo, node_hi;    // node range of this level
 	int slot0, nslots;       // partial-list slot of split 0 of this level; slots per query over all levels
 	int level0, level_ratio; // level plan (scan_levels)
+	int seed;                // 1: level 0 goes to scan_seed_kernel (see scan_plan)
 	int wide;                // > 0: levels of at least this many nodes go to scan_wide_kernel (k <= kWideMaxK); see scan_plan
 	unsigned long long *thr_g;     // [nq] smallest k-th key published by any split, ~0 before the launch
 	unsigned long long *dbg;       // MVDB_SCAN_DEBUG builds: 8 counters (see tools/scan_debug.py)
@@ -702,9 +703,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 }
 
 // k-way merge of the sorted partial lists of one query: one wave per query, lane l owns slots
-// l, l + 64, ...; k rounds of "smallest key above the last one taken" (keys are unique: ids differ).
+// l, l + 64, ...; k rounds of "smallest key not yet taken" (keys are unique: ids differ).  The first
+// kMergeCache slots of a lane keep their next kMergeDepth keys in registers, loaded up front, so a round is a
+// wave reduction over registers; only a slot that wins kMergeDepth times in a row reloads (a round that walks global
+// memory costs a dependent L2 round trip: that was 12-33 us per merge, seven merges per sweep).  Slots beyond
+// the cached ones (small batches: up to 512 node splits per level) are walked as before.
 // FINAL: write ids / values / count.  Otherwise: thr_g[q] = the k-th smallest key seen so far
 // ("k keys <= this bound exist"; the later levels visit other nodes, so no later key equals it).
+constexpr int kMergeCache = 4, kMergeDepth = 2;
+
 template <bool FINAL>
 __global__ __launch_bounds__(256) void scan_merge_kernel(ScanArgs a, int slots_used)
 {
@@ -713,12 +720,29 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(ScanArgs a, int slots_u
 	if (qi >= a.nq) return;
 	const unsigned long long *pk = a.part_key + (size_t)qi * a.nslots * a.k;
 	const int32_t *pn = a.part_n + (size_t)qi * a.nslots;
+	int cn[kMergeCache], cpos[kMergeCache];  // list length; index of the key in hk[c][0]
+	unsigned long long hk[kMergeCache][kMergeDepth];
+#pragma unroll
+	for (int c = 0; c < kMergeCache; c++) {
+		const int s = lane + 64 * c;
+		cn[c] = s < slots_used ? pn[s] : 0;
+		cpos[c] = 0;
+	}
+	auto fill = [&](int c) {  // hk[c][*] = keys cpos[c] .. cpos[c] + depth - 1 of the slot
+		const unsigned long long *p = pk + (size_t)(lane + 64 * c) * a.k + cpos[c];
+#pragma unroll
+		for (int d = 0; d < kMergeDepth; d++) hk[c][d] = cpos[c] + d < cn[c] ? p[d] : ~0ull;
+	};
+#pragma unroll
+	for (int c = 0; c < kMergeCache; c++) fill(c);
 	unsigned long long last = 0;
 	bool have_last = false;
 	int out = 0;
 	for (; out < a.k; out++) {
-		unsigned long long best = ~0ull;
-		for (int s = lane; s < slots_used; s += 64) {
+		unsigned long long best = hk[0][0];
+#pragma unroll
+		for (int c = 1; c < kMergeCache; c++) best = hk[c][0] < best ? hk[c][0] : best;
+		for (int s = lane + 64 * kMergeCache; s < slots_used; s += 64) {
 			const int n = pn[s];
 			for (int i = 0; i < n; i++) {
 				const unsigned long long key = pk[(size_t)s * a.k + i];
@@ -737,6 +761,15 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(ScanArgs a, int slots_u
 		if (best == ~0ull) break;
 		last = best;
 		have_last = true;
+#pragma unroll
+		for (int c = 0; c < kMergeCache; c++) {
+			const bool won = hk[c][0] == best;  // at most one slot of one lane
+#pragma unroll
+			for (int d = 0; d + 1 < kMergeDepth; d++) hk[c][d] = won ? hk[c][d + 1] : hk[c][d];
+			hk[c][kMergeDepth - 1] = won ? ~0ull : hk[c][kMergeDepth - 1];
+			cpos[c] += won ? 1 : 0;
+			if (hk[c][0] == ~0ull && cpos[c] < cn[c]) fill(c);  // the cached keys are used up and the list has more (rare)
+		}
 		if (FINAL && lane == 0) {
 			const int val = (int)((unsigned)(best >> 32) ^ 0x80000000u);
 			a.out_ids[(size_t)qi * a.k + out] = (int)(unsigned)best;
@@ -784,10 +817,12 @@ __host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 =
 
 }  // namespace mvdb
 #include "scan_wide.hip.hpp"
+#include "scan_seed.hip.hpp"
 namespace mvdb {
 
 }  // namespace mvdb
 #include "scan_wide.hip.hpp"
+#include "scan_seed.hip.hpp"
 namespace mvdb {
 
 // The plan of one sweep: per level its node range, which kernel takes it, its node splits and first list slot.
@@ -795,11 +830,11 @@ namespace mvdb {
 // first levels, where almost every element is a candidate, stay with scan_kernel (its candidate path is overlapped
 // by the partner wave, the wide kernel's is not).
 struct ScanLevel {
-	int lo, hi, wide, qtiles, s2, nsplit, slot0;
+	int lo, hi, wide, seed, qtiles, s2, nsplit, slot0;
 };
 constexpr int kWideMinLevel = 100000;
 
-__host__ inline int scan_plan(int N, int nq, int wide, int level0, int ratio, ScanLevel (&lv)[kScanMaxLevels], int *total_slots)
+__host__ inline int scan_plan(int N, int nq, int wide, int seed, int level0, int ratio, ScanLevel (&lv)[kScanMaxLevels], int *total_slots)
 {
 	int ends[kScanMaxLevels];
 	const int levels = scan_levels(N, ends, level0, ratio, wide);
@@ -809,9 +844,10 @@ __host__ inline int scan_plan(int N, int nq, int wide, int level0, int ratio, Sc
 		v.lo = lo;
 		v.hi = ends[l];
 		v.wide = (wide > 0 && v.hi - v.lo >= wide) ? 1 : 0;
+		v.seed = (l == 0 && seed && !v.wide && v.hi - v.lo <= kSeedMaxNodes) ? 1 : 0;  // level 0: scan_seed_kernel, one list per query
 		v.qtiles = v.wide ? (nq + kWideQB - 1) / kWideQB : (nq + kScanQB - 1) / kScanQB;
 		v.s2 = v.wide ? scan_wide_s2_for(nq) : scan_s2_for(nq);
-		v.nsplit = 8 * v.s2;
+		v.nsplit = v.seed ? 1 : 8 * v.s2;
 		v.slot0 = slot;
 		slot += v.nsplit;
 		lo = ends[l];
@@ -835,6 +871,9 @@ inline bool launch_scan_t(const ScanArgs &a0, hipStream_t s)
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KS, METRIC, CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                        (int)lds_std) != hipSuccess)
 			return false;
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_seed_kernel<KS, METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                        (int)kSeedLdsBytes) != hipSuccess)
+			return false;
 		if constexpr (HAS_WIDE) {
 			if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_wide_kernel<WKS, METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize,
 			                        (int)lds_wide) != hipSuccess)
@@ -845,7 +884,7 @@ inline bool launch_scan_t(const ScanArgs &a0, hipStream_t s)
 	if (a0.wide && (!HAS_WIDE || a0.k > kWideMaxK)) return false;
 	ScanLevel lv[kScanMaxLevels];
 	int total = 0;
-	const int levels = scan_plan(a0.ix.max_elements, a0.nq, a0.wide, a0.level0, a0.level_ratio, lv, &total);
+	const int levels = scan_plan(a0.ix.max_elements, a0.nq, a0.wide, a0.seed, a0.level0, a0.level_ratio, lv, &total);
 	if (total > a0.nslots) return false;
 	ScanArgs a = a0;
 	for (int l = 0; l < levels; l++) {
@@ -856,7 +895,9 @@ inline bool launch_scan_t(const ScanArgs &a0, hipStream_t s)
 		a.nsplit = lv[l].nsplit;
 		a.slot0 = lv[l].slot0;
 		a.nodes_per_split = (((a.node_hi - a.node_lo + a.nsplit - 1) / a.nsplit) + kScanStage - 1) / kScanStage * kScanStage;
-		if (lv[l].wide) {
+		if (lv[l].seed) {
+			hipLaunchKernelGGL((scan_seed_kernel<KS, METRIC>), dim3((a.nq + 15) / 16), dim3(256), kSeedLdsBytes, s, a);
+		} else if (lv[l].wide) {
 			if constexpr (HAS_WIDE)
 				hipLaunchKernelGGL((scan_wide_kernel<WKS, METRIC>), dim3(a.qtiles * a.nsplit), dim3(256), lds_wide, s, a);
 		} else {
