@@ -70,6 +70,25 @@ __device__ __forceinline__ int scan_max3(int x, int y, int z)
 	const int m = x > y ? x : y;
 	return m > z ? m : z;
 }
+// LDS stores and the slot counter of the candidate path, as inline assembly: before an LDS store or atomic the
+// compiler waits for EVERY outstanding LDS-DMA load (it cannot tell that the tile buffers and the selection
+// structures never overlap), i.e. for the tile fill in flight -- a full memory round trip per candidate call.
+// LDS operations of a wave execute in order, so later plain loads see these stores without further ado.
+__device__ __forceinline__ unsigned wide_lds_off(const void *p) { return (unsigned)(size_t)p; }  // low half of a flat LDS address = LDS offset
+__device__ __forceinline__ int wide_lds_add1(int *p)
+{
+	int old;
+	asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(wide_lds_off(p)), "v"(1) : "memory");
+	return old;
+}
+__device__ __forceinline__ void wide_lds_store64(unsigned long long *p, unsigned long long v)
+{
+	asm volatile("ds_write_b64 %0, %1" ::"v"(wide_lds_off(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wide_lds_store128(void *p, const v4i &v)
+{
+	asm volatile("ds_write_b128 %0, %1" ::"v"(wide_lds_off(p)), "v"(v) : "memory");
+}
 __device__ __forceinline__ void wide_mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 template <int KS, int METRIC>
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 			case 6: av4 = acc[3][0]; break;
 			default: av4 = acc[3][1]; break;
 			}
-			*st = av4;
+			wide_lds_store128(st, av4);
 			const int cc = (t & 1) ? c1 : c0, vn = (t & 1) ? vn1 : vn0;
 			unsigned pm = (av4[0] + cc >= 0 ? 1u : 0u) | (av4[1] + cc >= 0 ? 2u : 0u) | (av4[2] + cc >= 0 ? 4u : 0u) | (av4[3] + cc >= 0 ? 8u : 0u);
 			const int row0 = (grp * kWideGR + (t >> 1)) * 16 + (lane >> 4) * 4;
@@ -301,11 +320,11 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 					const int row = row0 + i;
 					// four LDS operations in flight at once: with one wave per SIMD each round trip is paid in full
 					const int sv = stage[lane * 4 + i], gv = G_s[pgen * kWideWR + row], qv = qq_s[row];
-					const int slot = atomicAdd(&cnt[row], 1);
+					const int slot = wide_lds_add1(&cnt[row]);
 					const int dot = sv - gv;
 					const int val = METRIC == 0 ? qv + vn - 2 * dot : -dot;
 					if (slot < kWideCap) {
-						list[row * kWideStride + slot] = scan_key(val, node);
+						wide_lds_store64(&list[row * kWideStride + slot], scan_key(val, node));
 						pm &= pm - 1;
 					}
 					ovf = slot + 1 >= kWideCap;
