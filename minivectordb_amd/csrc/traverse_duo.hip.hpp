@@ -67,6 +67,9 @@ namespace mvdb {
 #ifndef MVDB_DUO_PREF
 #define MVDB_DUO_PREF 1  // fetch the list of the root the pop leaves at pop time: +1-1.5 % with three waves (none with two)
 #endif
+#ifndef MVDB_DUO_SPEC_LIST
+#define MVDB_DUO_SPEC_LIST 0  // guess the next candidate BEFORE the wait for the previous admission and fetch its list under that wait: bit-exact, no gain (2.69 vs 2.64 ms solo, 404 k both with three batches in flight) -- the admission chain, not the list fetch, sets the period
+#endif
 #ifndef MVDB_DUO_POLL_SLEEP
 #define MVDB_DUO_POLL_SLEEP 1  // s_sleep argument (x64 cycles) between two polls of a mailbox
 #endif
@@ -291,11 +294,13 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		};
 
 		int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
+		int spec_id = -1, spec_nb = -1;  // list fetched ahead for the guess made before the channel wait
 		int sink = 0;                    // keeps the L2-warming loads alive
 		// neighbour list -> {visited test-and-set, rows of every listed neighbour} -> new ones into buffer b
 		auto mem_phase = [&](int c_id, int b) -> int {
 			int nb = -1;
 			if (pref_id == c_id) nb = pref_nb;
+			else if (MVDB_DUO_SPEC_LIST && spec_id == c_id) nb = spec_nb;
 			else {
 				if (lane < ix.m0) nb = ix.adj0[(size_t)c_id * (size_t)ix.m0 + lane];
 				background(6);
@@ -399,6 +404,36 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 			// the result wave pushes only after this pop's sift-down has left the heap
 			cpipe.drain();
 			if (!sift_pub) post_sift();
+			if (MVDB_DUO_SPEC_LIST) {
+				// A HINT, never a decision: the pop below cannot happen before list e-1 has been admitted and pushed, and
+				// that wait is the longest idle stretch of this wave.  Guess who is popped next from what is visible now
+				// -- the minimum of this list against the current root's children (read while the other waves may still
+				// be pushing: any entry ever seen there is a whole, valid {key, id}) -- and fetch that node's list under
+				// the wait.  Lists never change during a launch, so the fetched words are used iff the exact choice made
+				// after the pop names the same node; otherwise they are dropped.
+				int g_id = -1;
+				if (!have_c) {
+					if (cand_size >= 1) g_id = rfl((int)cand_h[1].y);
+				} else {
+					const u32x4_t kids = *reinterpret_cast<const volatile lds_u32x4 *>((size_t)((unsigned)(size_t)cand_h + 16u));
+					const unsigned kl = (unsigned)rfl((int)kids.x), kr = (unsigned)rfl((int)kids.z);
+					const int il = rfl((int)kids.y), ir = rfl((int)kids.w);
+					unsigned k_key = 0xffffffffu;
+					int k_id = -1;
+					if (cand_size >= 2) {
+						const bool right = cand_size >= 3 && kr < kl;
+						k_key = right ? kr : kl;
+						k_id = right ? ir : il;
+					}
+					const bool list_wins = n > 0 && (res_size < ef || d_min < worst) && d_min < k_key;
+					g_id = list_wins ? min_id : k_id;
+				}
+				if (g_id != c_id && g_id != pref_id && (unsigned)g_id < (unsigned)ix.max_elements) {
+					spec_id = g_id;
+					spec_nb = -1;
+					if (lane < ix.m0) spec_nb = ix.adj0[(size_t)g_id * (size_t)ix.m0 + lane];
+				}
+			}
 			// ---- record e-1 must be admitted and pushed before the pop
 			u32x4_t ch;
 			for (int spin = 0;;) {
@@ -478,7 +513,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 					o_key = (unsigned)__builtin_amdgcn_readlane((int)cpipe.root_key, owner);
 					o_id = __builtin_amdgcn_readlane((int)cpipe.root_id, owner);
 				}
-				if (MVDB_DUO_PREF) {
+				if (MVDB_DUO_PREF && !(MVDB_DUO_SPEC_LIST && spec_id == o_id) && pref_id != o_id) {
 					pref_id = o_id;  // its list is needed next unless a new neighbour undercuts it
 					pref_nb = -1;
 					if (lane < ix.m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)ix.m0 + lane];
