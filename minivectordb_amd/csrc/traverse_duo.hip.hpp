@@ -61,6 +61,9 @@ namespace mvdb {
 #ifndef MVDB_DUO_SPEC_ROWS
 #define MVDB_DUO_SPEC_ROWS 1  // gather the rows of every listed neighbour together with the visited test
 #endif
+#ifndef MVDB_DUO_SPEC_ADAPT
+#define MVDB_DUO_SPEC_ADAPT 1  // ... but per query only while at least half of the recently listed neighbours were new (see mem_phase)
+#endif
 #ifndef MVDB_DUO_WARM
 #define MVDB_DUO_WARM 0  // touch the listed neighbours' own lists (L2 warm-up for the next pop): +25 % HBM traffic, no gain measured
 #endif
@@ -295,6 +298,15 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 
 		int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
 		int spec_id = -1, spec_nb = -1;  // list fetched ahead for the guess made before the channel wait
+		// Rows of every listed neighbour together with the visited test save a memory round trip when nearly all of
+		// them are new (i.i.d. data at ef ~ 1200: 95 %), and waste row traffic and dot products when few are (clustered
+		// data: 4 of 32).  Both orders give the same buffers, so the choice is free: a decaying count of listed and new
+		// neighbours of this query's last few lists picks rows-with-visited while at least half were new.
+		int seen_listed = 0, seen_new = 0;
+		auto note_list = [&](int listed, int fresh) {
+			seen_listed += listed - (seen_listed >> 2);
+			seen_new += fresh - (seen_new >> 2);
+		};
 		int sink = 0;                    // keeps the L2-warming loads alive
 		// neighbour list -> {visited test-and-set, rows of every listed neighbour} -> new ones into buffer b
 		auto mem_phase = [&](int c_id, int b) -> int {
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 				old = vis.probe(nb);
 				if (MVDB_DUO_SPEC_ROWS) all_ids[lane] = nb;
 			}
-			if (!MVDB_DUO_SPEC_ROWS) {
+			if (!MVDB_DUO_SPEC_ROWS || (MVDB_DUO_SPEC_ADAPT && 2 * seen_new < seen_listed)) {
 				// rows of the NEW neighbours only, after the visited words are back
 				background(6);
 				const bool isnew = nb >= 0 && !vis.seen(old, nb);
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 				const unsigned long long nm = __ballot(isnew);
 				const int n = __builtin_popcountll(nm);
 				vlog.append(isnew, nb, nm, n, lane);
+				note_list(cnt, n);
 				if (n == 0) return 0;
 				int *ids = ids_b + 64 * b;
 				if (isnew) ids[__builtin_popcountll(nm & ((1ull << lane) - 1))] = nb;
@@ -364,6 +377,7 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 			const unsigned long long nm = __ballot(isnew);
 			const int n = __builtin_popcountll(nm);
 			vlog.append(isnew, nb, nm, n, lane);
+			note_list(cnt, n);
 			if (isnew) {
 				const int pos = __builtin_popcountll(nm & ((1ull << lane) - 1));
 				ids_b[64 * b + pos] = nb;
