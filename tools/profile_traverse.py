@@ -19,17 +19,22 @@ if __name__ == "__main__":
         print(build_prof()); sys.exit(0)
     _native.LIB_PATH = os.path.join(ROOT, "minivectordb_amd", "lib", "libmvdb_hip_prof.so")
     from minivectordb_amd import HipBridge, resolve_preset, derive_search_params
+    clustered = "--clustered" in sys.argv  # bench.py's second dataset (4096 Gaussian clusters) instead of i.i.d. rows
+    if clustered:
+        sys.argv.remove("--clustered")
+        import bench
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     nq, dim = 1000, 384
     p = resolve_preset("balanced")
     rng = np.random.default_rng(12345)
-    base = rng.standard_normal((n, dim), dtype=np.float32)
+    base = bench.make_rows(n, dim, 12345 + 777, True) if clustered else rng.standard_normal((n, dim), dtype=np.float32)
     b = HipBridge(); b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], capacity=n, seed=42, resultsCap=4096))
     qn, q8 = b.prepareQueries(base)
     b.buildGpu(q8)
     waves = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     b.setTuning(traverse_waves=waves)
-    q = np.random.default_rng(54321).standard_normal((nq, dim), dtype=np.float32)
+    q = (bench.make_queries(1, nq, dim, 54321, qn, True)[0] if clustered
+         else np.random.default_rng(54321).standard_normal((nq, dim), dtype=np.float32))
     _, qi8 = b.prepareQueries(q)
     tk, ef, ann_k = derive_search_params(10, p)
     b.setEfSearch(ef)
