@@ -13,3 +13,9 @@ find gpurun_out/prof_scan -name "*kernel_stats.csv" -exec cp {} gpurun_out/scan_
 python tools/trace_launches.py gpurun_out/prof_scan | tail -14 > gpurun_out/scan_launches.txt
 find gpurun_out/prof_scan -name "*kernel_trace.csv" -delete
 cut -c1-300 gpurun_out/bench_scan_rocprof.json
+rm -rf gpurun_out/prof_hnsw
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hnsw -o hnsw -- python bench.py --cpu-sample 0 --second-dataset none --sustain-s 0 --no-pcie > gpurun_out/bench_hnsw_rocprof.json 2> gpurun_out/bench_hnsw_rocprof.err || { tail gpurun_out/bench_hnsw_rocprof.err; exit 1; }
+find gpurun_out/prof_hnsw -name "*kernel_stats.csv" -exec cp {} gpurun_out/hnsw_kernel_stats.csv \;
+python tools/kernel_trace_table.py $(find gpurun_out/prof_hnsw -name "*kernel_trace.csv" | head -1) traverse_duo 20 gpurun_out/traverse_launches.csv
+find gpurun_out/prof_hnsw -name "*kernel_trace.csv" -delete
+cut -c1-300 gpurun_out/bench_hnsw_rocprof.json
