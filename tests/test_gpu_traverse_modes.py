@@ -167,3 +167,22 @@ def test_aborted_query_is_reported_not_returned_empty(gpu, visited_mode):
         gi, gl, gn = b.queryMany(q, 10, 140, 1200)           # and the handle keeps working
         assert np.array_equal(gn, on) and np.array_equal(gi, oi) and np.array_equal(gl.view(np.uint64), ol.view(np.uint64))
     b.setTuning()
+
+
+def test_clustered_rows_mode_switch(gpu):
+    # Gaussian clusters: early in a query nearly every listed neighbour is new (rows are gathered together with
+    # the visited test), later most are visited already (rows after the visited words): the per-query switch
+    # between the two orders (traverse_duo.hip.hpp, MVDB_DUO_SPEC_ADAPT) must not change a bit.
+    n, dim, m, efc = 6000, 64, 16, 100
+    rng = np.random.default_rng(77)
+    centers = rng.standard_normal((48, dim), dtype=np.float32)
+    x = centers[rng.integers(0, 48, n)] + np.float32(0.3) * rng.standard_normal((n, dim), dtype=np.float32)
+    base = O.normalize_rows_f32(x)
+    b8 = O.quantize_rows_i8(base)
+    ix = O.OracleIndex(dim, m, efc, n, seed=7)
+    ix.insert_many(np.arange(n, dtype=np.int32), b8)
+    b = _bridge(ix, dim, m, efc)
+    q = base[rng.integers(0, n, 64)] + np.float32(0.05) * rng.standard_normal((64, dim), dtype=np.float32)
+    q8 = O.quantize_rows_i8(O.normalize_rows_f32(q.astype(np.float32)))
+    for k, ef in [(10, 64), (300, 300), (1200, 1200)]:
+        _same(b, ix, q8, k, ef)
