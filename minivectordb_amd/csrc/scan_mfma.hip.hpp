@@ -820,11 +820,6 @@ __host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 =
 #include "scan_seed.hip.hpp"
 namespace mvdb {
 
-}  // namespace mvdb
-#include "scan_wide.hip.hpp"
-#include "scan_seed.hip.hpp"
-namespace mvdb {
-
 // The plan of one sweep: per level its node range, which kernel takes it, its node splits and first list slot.
 // Levels of at least a.wide nodes (kWideMinLevel when the engine turns it on) go to scan_wide_kernel; the small
 // first levels, where almost every element is a candidate, stay with scan_kernel (its candidate path is overlapped
