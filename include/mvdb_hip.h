@@ -205,6 +205,9 @@ int mvdb_query_many(mvdb_index *h, const float *q_f32, int nq, int topk, int ef_
 int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, int topk, int ef_search,
                            int ann_k, const uint32_t *allow);
 int mvdb_query_many_wait(mvdb_index *h, int slot, int32_t *out_ids, double *out_l2, int32_t *out_n);
+/* nq / topk of the batch a busy slot holds (what the wait will copy: size the output arrays from THIS);
+ * 0 when the slot is idle or out of range.  No reference counterpart. */
+int mvdb_query_many_slot_shape(mvdb_index *h, int slot, int *nq, int *topk);
 /* ef / annK derivation (mini-vector-db.ts:568-576) and the results-cap growth
  * rule ensureResultsCapAtLeast (:1160-1170), host-only helpers */
 void mvdb_derive_params(int topk_in, int base_ef_search, int rerank_multiplier, int max_ann_k, int *topk,
@@ -265,6 +268,9 @@ void mvdb_upload_counters(const mvdb_index *h, long long *out3);
 /* Test hook: query index `query` of every following traversal launch takes the abort
  * path (-1 = off). */
 void mvdb_debug_inject_abort(mvdb_index *h, int query);
+/* Test hook: mvdb_build_gpu / mvdb_append_gpu fail before GPU pass `pass` (-1 = off), as an allocation or launch
+ * failure would; the nodes not linked yet are taken back (status 0, the index keeps what it reports). */
+void mvdb_debug_inject_build_failure(mvdb_index *h, int pass);
 /* Synchronise `stream` and give its per-stream scratch set back (call before
  * destroying a stream that was passed to a `_dev` entry point). */
 int mvdb_release_stream(mvdb_index *h, void *stream);

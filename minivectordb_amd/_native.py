@@ -64,6 +64,7 @@ SYMBOLS = [
     ("mvdb_query_many", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mvdb_query_many_submit", _i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     ("mvdb_query_many_wait", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("mvdb_query_many_slot_shape", _i, [_vp, _i, _vp, _vp]),
     ("mvdb_derive_params", None, [_i, _i, _i, _i, _vp, _vp, _vp]),
     ("mvdb_ensure_results_cap_at_least", None, [_vp, _i]),
     ("mvdb_to_score", _d, [_d, _i]),
@@ -78,6 +79,7 @@ SYMBOLS = [
     ("mvdb_check_errors", _i, [_vp]),
     ("mvdb_upload_counters", None, [_vp, _vp]),
     ("mvdb_debug_inject_abort", None, [_vp, _i]),
+    ("mvdb_debug_inject_build_failure", None, [_vp, _i]),
     ("mvdb_release_stream", _i, [_vp, _vp]),
     ("mvdb_enable_timing", None, [_vp, _i]),
     ("mvdb_last_stage_ms", _f, [_vp, _i]),

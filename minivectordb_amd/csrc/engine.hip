@@ -226,6 +226,7 @@ int DeviceIndex::patch(const HostGraph &g, std::string &err)
 	if (nd > (size_t)N / 4) return 0;  // a full upload is cheaper
 	const int stride = view.row_stride;
 	// new nodes first: their codes are named by the lists of the other dirty nodes
+	int64_t new_lists = 0;  // upper lists the whole batch appends into the slack
 	for (int id : g.dirty) {
 		const int lvl = g.level[id];
 		if (lvl < 0) return 0;  // nodes never disappear (no delete in the ANN index)
@@ -234,7 +235,8 @@ int DeviceIndex::patch(const HostGraph &g, std::string &err)
 			continue;
 		}
 		if (has_dangling_) return 0;  // an untouched list may name this id: its canonical form changes with presence
-		if (n_lists_ + lvl > cap_lists_) return 0;
+		new_lists += lvl;
+		if (n_lists_ + new_lists > cap_lists_) return 0;  // slack exhausted: the full upload re-sizes it
 	}
 	for (int id : g.dirty) {
 		if (dev_level_[id] >= 0) continue;
@@ -368,6 +370,7 @@ struct mvdb_index {
 	int *err_host = nullptr;
 	int *err_dev = nullptr;
 	int inject_abort_q = -1;  // mvdb_debug_inject_abort
+	int inject_build_fail_pass = -1;  // mvdb_debug_inject_build_failure
 
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[4];
@@ -749,18 +752,28 @@ static int gpu_link_range(mvdb_index *h, const int8_t *packed, int first, int co
 		return 0;
 	}
 	if (max_block <= 0) max_block = 32768;
+	// a pass links max(64, min(max_block, linked / 32)) nodes: the request buffers are sized for that floor too
+	max_block = std::min(std::max(max_block, 64), std::max(n, 1));
+	int ef = g.cfg.ef_construction;
+	if (ef > kMaxEf) ef = kMaxEf;
+	const int cand_cap = std::max(std::min(2 * ef + 32, kMaxEf), ef);
+	const int bloom_log2 = ef <= 400 ? 16 : (ef <= 1200 ? 17 : 18);
+	const size_t lds = build_link_lds_bytes(ef, cand_cap, bloom_log2);
+	if (lds > 160 * 1024) {  // refused before the host graph is touched
+		h->set_error("mvdb_build_gpu: ef_construction too large for the LDS heaps");
+		return 0;
+	}
 	const auto t0 = clk::now();
 	const int linked0 = g.bulk_append_begin(packed, count, std::min(n, 2048));
 	const double prefix_s = std::chrono::duration<double>(clk::now() - t0).count();
 	double st[8] = {0, prefix_s, 0, 0, 0, 0, 0, (double)(linked0 - first)};
-	if (linked0 < n) {
+	// Everything below can fail (device memory, a copy, a launch): the nodes bulk_append_begin created but did not
+	// link are then taken back (HostGraph::bulk_abort), so the index holds exactly the nodes it reports and the
+	// caller may insert the rest by any other path.
+	auto gpu_part = [&]() -> int {
 		h->dev.release();  // the search mirror is stale anyway; its memory is needed at 10 M+
-		int ef = g.cfg.ef_construction;
-		if (ef > kMaxEf) ef = kMaxEf;
-		const int cand_cap = std::max(std::min(2 * ef + 32, kMaxEf), ef);
 		const int stride = (dim + 15) & ~15;
 		const int slots = m0 + (kMaxLayers - 1) * m;
-		max_block = std::min(max_block, n);
 		const size_t n_slots_max = (size_t)max_block * slots;
 		DevBuf b_vec, b_level, b_adj0, b_cnt0, b_off, b_upper, b_head, b_req, b_rem, b_next, b_tlist, b_misc;
 		int8_t *d_vec = static_cast<int8_t *>(b_vec.need((size_t)n * stride));
@@ -810,7 +823,7 @@ static int gpu_link_range(mvdb_index *h, const int8_t *packed, int first, int co
 		a.upper = d_upper;
 		a.ef = ef;
 		a.cand_cap = cand_cap;
-		a.bloom_log2 = ef <= 400 ? 16 : (ef <= 1200 ? 17 : 18);
+		a.bloom_log2 = bloom_log2;
 		a.slots = slots;
 		a.req = d_req;
 		a.rem = d_rem;
@@ -819,13 +832,12 @@ static int gpu_link_range(mvdb_index *h, const int8_t *packed, int first, int co
 		a.tlist = d_tlist;
 		a.tcount = reinterpret_cast<int32_t *>(d_misc);
 		a.stats = reinterpret_cast<unsigned long long *>(d_misc + 64);
-		const size_t lds = build_link_lds_bytes(ef, cand_cap, a.bloom_log2);
-		if (lds > 160 * 1024) {
-			h->set_error("mvdb_build_gpu: ef_construction too large for the LDS heaps");
-			return 0;
-		}
 		int passes = 0;
 		for (int linked = linked0; linked < n;) {
+			if (passes == h->inject_build_fail_pass) {  // test hook (mvdb_debug_inject_build_failure)
+				h->set_error("GPU builder: injected failure");
+				return 0;
+			}
 			const int block = std::min(n - linked, std::max(64, std::min(max_block, linked / 32)));
 			a.first = linked;
 			a.count = block;
@@ -861,6 +873,12 @@ static int gpu_link_range(mvdb_index *h, const int8_t *packed, int first, int co
 		st[4] = (double)dst[2];
 		st[5] = (double)dst[3];
 		st[6] = passes;
+		return 1;
+	};
+	if (linked0 < n && !gpu_part()) {
+		(void)hipDeviceSynchronize();
+		g.bulk_abort(n);
+		return 0;
 	}
 	g.bulk_end(n);
 	st[0] = std::chrono::duration<double>(clk::now() - t0).count();
@@ -1462,6 +1480,14 @@ int mvdb_query_many_submit(mvdb_index *h, int slot, const float *q_f32, int nq, 
 	return 1;
 }
 
+int mvdb_query_many_slot_shape(mvdb_index *h, int slot, int *nq, int *topk)
+{
+	if (slot < 0 || slot >= kStreamSets || !h->hs[slot].busy) return 0;
+	if (nq) *nq = h->hs[slot].nq;
+	if (topk) *topk = h->hs[slot].topk;
+	return 1;
+}
+
 int mvdb_query_many_wait(mvdb_index *h, int slot, int32_t *out_ids, double *out_l2, int32_t *out_n)
 {
 	if (slot < 0 || slot >= kStreamSets) {
@@ -1704,6 +1730,7 @@ void mvdb_upload_counters(const mvdb_index *h, long long *out3)
 }
 
 void mvdb_debug_inject_abort(mvdb_index *h, int query) { h->inject_abort_q = query; }
+void mvdb_debug_inject_build_failure(mvdb_index *h, int pass) { h->inject_build_fail_pass = pass; }
 
 int mvdb_release_stream(mvdb_index *h, void *stream)
 {

@@ -662,6 +662,8 @@ int HostGraph::bulk_append_begin(const int8_t *packed, int count, int min_linked
 	const int n = first + count;
 	version++;
 	dirty_all = true;
+	bulk_rng0_ = rng_state;  // bulk_abort() replays the draws of the nodes that stay
+	bulk_first_ = first;
 	std::memcpy(vec.data() + (size_t)first * cfg.dim, packed, (size_t)count * cfg.dim);
 	std::vector<int8_t> lv((size_t)count);
 	size_t upper_total = 0;
@@ -691,6 +693,29 @@ int HostGraph::bulk_append_begin(const int8_t *packed, int count, int min_linked
 void HostGraph::bulk_end(int n)
 {
 	element_count = std::min(n, max_elements);
+	version++;
+}
+
+// Undo bulk_append_begin for the nodes it created but did not link (ids element_count .. n - 1), after a failed
+// GPU pass: they become absent again, their upper lists (the tail of `upper`: node blocks were created in id
+// order) are dropped, and the RNG stream is put where a sequential insert of the linked nodes would have left
+// it, so the ids can be inserted again by any path and draw the levels they would have drawn.
+void HostGraph::bulk_abort(int n)
+{
+	const int linked = element_count;
+	n = std::min(n, max_elements);
+	int64_t cut = -1;
+	for (int id = linked; id < n; id++) {
+		if (upper_off[id] >= 0 && (cut < 0 || upper_off[id] < cut)) cut = upper_off[id];
+		level[id] = -1;
+		cnt0[id] = 0;
+		std::fill_n(adj0.begin() + (size_t)id * cfg.m0(), cfg.m0(), -1);
+		upper_off[id] = -1;
+	}
+	if (cut >= 0) upper.resize((size_t)cut);
+	rng_state = bulk_rng0_;
+	for (int i = bulk_first_; i < linked; i++) (void)random_level();
+	dirty_all = true;
 	version++;
 }
 

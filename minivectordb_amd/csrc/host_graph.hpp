@@ -115,12 +115,14 @@ public:
 	int bulk_begin(const int8_t *packed, int n, int prefix);
 	int bulk_append_begin(const int8_t *packed, int count, int min_linked);
 	void bulk_end(int n);
+	void bulk_abort(int n);  // after a failure between the two: the unlinked nodes are taken back
 
 private:
 	std::unique_ptr<BuildScratch> main_;
 	std::unique_ptr<std::atomic<uint8_t>[]> locks_;
 	std::atomic<uint8_t> global_lock_{0};
-	std::vector<int8_t> pending_level_;
+	uint32_t bulk_rng0_ = 0;  // RNG state and first id of the bulk append in progress (bulk_abort)
+	int bulk_first_ = 0;
 
 	int random_level();                                 // hnsw.ts:416-420
 	void create_node(int id, int lvl);

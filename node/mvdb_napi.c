@@ -335,6 +335,10 @@ static napi_value WaitMany(napi_env env, napi_callback_info info)
 	if (!h) return NULL;
 	int slot = get_i32(env, a[1]), nq = get_i32(env, a[2]), topk = get_i32(env, a[3]);
 	if (nq < 0 || topk < 0) return throw_type(env, "waitMany: nq / topk must not be negative");
+	/* the wait copies what was SUBMITTED on the slot: the output arrays are sized from that, never from the caller */
+	int s_nq = 0, s_topk = 0;
+	if (mvdb_query_many_slot_shape(h, slot, &s_nq, &s_topk) && (s_nq != nq || s_topk != topk))
+		return throw_type(env, "waitMany: nq / topk differ from the batch submitted on this slot");
 	size_t tk = topk > 0 ? (size_t)topk : 1;
 	void *ids, *l2, *n;
 	napi_value t_ids = make_typed(env, napi_int32_array, (size_t)nq * tk, 4, &ids);

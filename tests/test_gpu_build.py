@@ -113,6 +113,49 @@ def test_gpu_build_small_and_limits(gpu):
     # self-hit: every stored row finds itself first
     gi, gd, gc = b.searchManyArrays(b8[:64], 1)
     assert (gd[:, 0] == 0).all()
+    # max_block below the 64-node floor of a pass: the request buffers are sized for the floor
+    b = HipBridge()
+    b.init(dict(dim=100, m=12, ef=150, capacity=6000, seed=3))
+    st = b.buildGpu(b8[:4000], max_block=8)
+    assert b.elementCount() == 4000 and st["passes"] >= 30
+    ix = O.OracleIndex(100, 12, 150, 8, seed=1)
+    assert ix.load_bytes(b.saveBytes())
+    ix.set_ef_search(80); b.setEfSearch(80)
+    oi, od, oc, _ = ix.search_many(q8, 50, threads=8)
+    gi, gd, gc = b.searchManyArrays(q8, 50)
+    assert np.array_equal(gc, oc) and np.array_equal(gi, oi)
+
+
+def test_gpu_build_failure_takes_the_unlinked_nodes_back(gpu):
+    """A failure after the host prefix (device memory, a copy, a launch; forced through
+    mvdb_debug_inject_build_failure) must leave the index holding exactly the nodes it reports: the rest absent
+    again, the RNG stream where sequential inserts of the linked nodes would have left it -- so inserting the
+    remaining ids through insert() gives the levels one build over all the data gives."""
+    from minivectordb_amd import HipBridge, MvdbError
+    dim, n = 48, 9000
+    b8 = O.quantize_rows_i8(gaussian_unit(n, dim, 21))
+    cfg = dict(dim=dim, m=8, ef=60, capacity=n, seed=5)
+    whole = HipBridge()
+    whole.init(cfg)
+    whole.buildGpu(b8)
+    b = HipBridge()
+    b.init(cfg)
+    b._L.mvdb_debug_inject_build_failure(b.handle, 3)
+    with pytest.raises(MvdbError, match="injected"):
+        b.buildGpu(b8)
+    b._L.mvdb_debug_inject_build_failure(b.handle, -1)
+    k = b.elementCount()
+    assert 2048 <= k < n                                       # the host prefix stays, nothing beyond it
+    recs = D.walk(b.saveBytes())
+    assert [r[0] for r in recs] == list(range(k))
+    ix = O.OracleIndex(dim, 8, 60, 8, seed=1)
+    assert ix.load_bytes(b.saveBytes())                        # a consistent V3 dump
+    b.appendGpu(b8[k:])                                        # the remaining ids go in by any path
+    assert b.elementCount() == n
+    ref = D.walk(whole.saveBytes())
+    assert [(r[0], r[1]) for r in D.walk(b.saveBytes())] == [(r[0], r[1]) for r in ref]   # levels of ONE build
+    gi, gd, gc = b.searchManyArrays(b8[:64], 1)
+    assert (gd[:, 0] == 0).all()
 
 
 def test_gpu_build_is_deterministic(gpu):

@@ -97,3 +97,28 @@ def test_patch_falls_back_when_a_foreign_dump_names_absent_ids(gpu):
     b.insertManyPacked(np.array(named, np.int32), vec.reshape(-1), dim)
     _same_answers(b, _fresh(b.saveBytes(), dim, m, efc), q8, 100, 100)
     assert b.uploadCounters()["full_uploads"] == 2
+
+
+def test_patch_takes_the_full_upload_when_a_batch_outgrows_the_upper_slack(gpu):
+    """The device keeps max(4096, lists/8) spare upper lists; a dirty batch whose SUMMED levels exceed what is left
+    must take the full upload (which re-sizes the slack) -- not pass a per-node check and write past the array."""
+    from minivectordb_amd import HipBridge
+    dim, m, efc, n, cap = 32, 8, 40, 3000, 16000
+    b8 = O.quantize_rows_i8(gaussian_unit(n, dim, 3))
+    b = HipBridge()
+    b.init(dict(dim=dim, m=m, ef=efc, capacity=cap, seed=42))
+    b.insertManyPacked(np.arange(n, dtype=np.int32), b8.reshape(-1), dim)
+    b.setResultsCap(4096)
+    q8 = O.quantize_rows_i8(gaussian_unit(64, dim, 5))
+    b.setEfSearch(100)
+    b.searchManyArrays(q8, 100)
+    assert b.uploadCounters()["full_uploads"] == 1
+    nxt, seen_second = n, False
+    for rnd in range(9):                      # ~0.875 upper lists per insert: 9 x 700 inserts cross 4096 lists of slack
+        ids = np.arange(nxt, nxt + 700, dtype=np.int32)
+        nxt += 700
+        b.insertManyPacked(ids, O.quantize_rows_i8(gaussian_unit(700, dim, 300 + rnd)).reshape(-1), dim)
+        _same_answers(b, _fresh(b.saveBytes(), dim, m, efc), q8, 100, 100)
+        seen_second = seen_second or b.uploadCounters()["full_uploads"] >= 2
+    c = b.uploadCounters()
+    assert seen_second and c["full_uploads"] == 2 and c["patches"] >= 5, c

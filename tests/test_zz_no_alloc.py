@@ -59,6 +59,35 @@ def test_noalloc_equals_search_many_dev(gpu):
         assert np.array_equal(dist_a.view(np.uint32), od.view(np.uint32))
     assert L.mvdb_check_errors(b.handle) == 1
 
+    # The property itself, not only the output: under stream capture (error mode "global") a hipMalloc, hipFree or
+    # synchronisation anywhere in the call fails the capture.  Timing is switched on for the handle, so an event
+    # pair created per launch (StageTimer) would show as well.  The replayed graph must give the same bits.
+    L.mvdb_enable_timing(b.handle, 1)
+    nq, k = q_small.shape[0], 300
+    qd = torch.from_numpy(q_small).to(dev)
+    ids = torch.full((nq, k), -7, dtype=torch.int32, device=dev)
+    dist = torch.full((nq, k), -7.0, dtype=torch.float32, device=dev)
+    cnt = torch.full((nq,), -7, dtype=torch.int32, device=dev)
+    ctr = torch.full((nq, 4), -7, dtype=torch.int32, device=dev)
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    vp = C.c_void_p
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize(dev)
+    with torch.cuda.graph(g):
+        ok = L.mvdb_search_many_dev_noalloc(b.handle, vp(qd.data_ptr()), nq, k, vp(ids.data_ptr()), vp(dist.data_ptr()),
+                                            vp(cnt.data_ptr()), vp(ctr.data_ptr()),
+                                            vp(torch.cuda.current_stream(dev).cuda_stream))
+    assert ok == 1, L.mvdb_last_error(b.handle)
+    for _ in range(2):
+        ids.fill_(-7); cnt.fill_(-7)
+        g.replay()
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(cnt.cpu().numpy(), cnt_a) and np.array_equal(ids.cpu().numpy(), ids_a)
+        assert np.array_equal(dist.cpu().numpy().view(np.uint32), dist_a.view(np.uint32))
+    assert torch.cuda.mem_get_info(dev)[0] >= free_before - (8 << 20)     # the graph object itself, nothing per call
+    L.mvdb_enable_timing(b.handle, 0)
+    del g
+
     # beyond the static scratch: 4000 nodes -> 512 B of bitmap per query -> 131072 queries fit, 140000 do not
     too_many = torch.zeros((140000, 384), dtype=torch.int8, device=dev)
     ok, *_ = _call(L.mvdb_search_many_dev_noalloc, b, too_many, 140000, 1, torch, dev)
