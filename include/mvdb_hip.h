@@ -246,9 +246,12 @@ int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, i
 
 /* ---- engine state beyond the WASM surface ---------------------------------- */
 /* Kernel variants of the timed path (handle state, read at launch): traverse_waves
- * 0 = default (3 waves per query when M_MAX0 <= 64), 1/2/3 force a variant (all
- * bit-identical, tests/test_gpu_traverse_modes.py); rerank_waves 0 = default (4),
- * 2 = small workgroups that fit beside a running traversal.  No reference counterpart. */
+ * 0 = default = 4 = the lean path when M_MAX0 <= 64 (one wave per query, result keys only, the
+ * result heap of hnsw.ts:233-325 replayed from the admission log by a second launch;
+ * csrc/traverse_lean.hip.hpp); 1/2/3 force the kernels that keep the result heap inside the
+ * traversal on that many waves per query (all bit-identical, tests/test_gpu_traverse_modes.py);
+ * rerank_waves 0 = default (4), 2 = small workgroups that fit beside a running traversal.
+ * No reference counterpart. */
 int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves);
 /* How the per-query visited bitmaps (hnsw.ts:480-495: the reference's visited stamps) get back to
  * zero between launches: 0 / 1 = one hipMemsetAsync per launch (N/8 bytes per query; the default),
@@ -271,6 +274,13 @@ void mvdb_debug_inject_abort(mvdb_index *h, int query);
 /* Test hook: mvdb_build_gpu / mvdb_append_gpu fail before GPU pass `pass` (-1 = off), as an allocation or launch
  * failure would; the nodes not linked yet are taken back (status 0, the index keeps what it reports). */
 void mvdb_debug_inject_build_failure(mvdb_index *h, int pass);
+/* Queries the lean traversal handed to the one-wave kernel since mvdb_create, by reason: out3 = {a distance
+ * beyond 16 bits (cannot happen for quantised unit vectors), admission log full, predicted candidate not at
+ * the root (an internal error: never observed)}.  They are answered correctly either way; the counters exist
+ * so that tests and benchmarks can tell which kernel ran.  No reference counterpart. */
+void mvdb_lean_fallbacks(const mvdb_index *h, long long *out3);
+/* Test hook: admissions the lean traversal may log per query (0 = the default, 12 * ef + 1024). */
+void mvdb_debug_set_lean_log_cap(mvdb_index *h, int cap);
 /* Synchronise `stream` and give its per-stream scratch set back (call before
  * destroying a stream that was passed to a `_dev` entry point). */
 int mvdb_release_stream(mvdb_index *h, void *stream);
@@ -278,7 +288,8 @@ int mvdb_release_stream(mvdb_index *h, void *stream);
 /* ---- measurement ----------------------------------------------------------- */
 /* average device time (ms) of the last launch of each stage, measured with HIP
  * events on the launching stream when timing is enabled. stage: 0 prep,
- * 1 traversal, 2 rerank, 3 scan. Returns <0 when no sample exists. */
+ * 1 traversal, 2 rerank, 3 scan, 4 result-heap replay of the lean traversal (with the
+ * fall-back launch in front of it). Returns <0 when no sample exists. */
 void mvdb_enable_timing(mvdb_index *h, int on);
 float mvdb_last_stage_ms(mvdb_index *h, int stage);
 /* launches and summed device ms of a stage since the last reset (one HIP event pair

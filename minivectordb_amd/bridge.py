@@ -133,6 +133,12 @@ class HipBridge:
         self._L.mvdb_upload_counters(self.handle, out)
         return dict(full_uploads=out[0], patches=out[1], nodes_patched=out[2])
 
+    def leanFallbacks(self) -> dict:
+        """Queries the lean traversal handed to the one-wave kernel, by reason (mvdb_lean_fallbacks)."""
+        out = (C.c_longlong * 3)()
+        self._L.mvdb_lean_fallbacks(self.handle, out)
+        return dict(big_key=out[0], log_full=out[1], mismatch=out[2])
+
     def _dim(self) -> int:
         return int(self._cfg["dim"])
 

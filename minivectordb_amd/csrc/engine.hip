@@ -20,6 +20,7 @@
 #include "scan.hip.hpp"
 #include "traverse.hip.hpp"
 #include "traverse_duo.hip.hpp"
+#include "traverse_lean.hip.hpp"
 #include "build_gpu.hip.hpp"
 
 using namespace mvdb;
@@ -316,6 +317,7 @@ static void *g_scratch_ptr[kMaxDevices];
 
 // --------------------------------------------------------------------------- handle
 constexpr int kStreamSets = 4;
+constexpr int kStages = 5;  // 0 prep, 1 traversal, 2 rerank, 3 scan, 4 result-heap replay (+ fall-back launch) of the lean path
 
 struct mvdb_index {
 	mvdb_config cfg{};
@@ -339,6 +341,7 @@ struct mvdb_index {
 		hipStream_t stream = nullptr;
 		bool used = false;
 		DevBuf visited, vis_log, qf, q8, ids, dist, cnt;
+		DevBuf adm_log, adm_n, flag;   // traverse_lean_kernel -> replay_kernel
 		bool vis_clean = false;        // the first vis_clean_bytes of `visited` are zero (log mode leaves them so)
 		size_t vis_clean_bytes = 0;
 		void *vis_seen_ptr = nullptr;  // the allocation (pointer, capacity) `vis_epoch` counts launches of
@@ -360,7 +363,10 @@ struct mvdb_index {
 		st_misc, scan_part, prof_buf;
 
 	// tuning knobs of the timed path (mvdb_set_tuning); 0 = the engine's default
-	int traverse_waves = 0;  // 1, 2 or 3 waves per query
+	int traverse_waves = 0;  // 0 / 4: lean kernel + replay (traverse_lean.hip.hpp); 1, 2 or 3: the kernels that keep the result heap in the traversal
+	int lean_log_cap = 0;    // test hook (mvdb_debug_set_lean_log_cap): admissions logged per query, 0 = 12 * ef + 1024
+	int *lean_stats_host = nullptr;  // device-mapped: queries the lean kernel handed to traverse_kernel, by reason
+	int *lean_stats_dev = nullptr;
 	int rerank_waves = 0;    // 2 or 4 waves per rerank workgroup
 	// visited-set clean-up (mvdb_set_visited_mode): 0 / 1 = one memset per launch (the default: measured faster at
 	// 1 M and at 10 M nodes), 2 = the kernel's log-and-clear
@@ -373,10 +379,10 @@ struct mvdb_index {
 	int inject_build_fail_pass = -1;  // mvdb_debug_inject_build_failure
 
 	bool timing = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[4];
-	float stage_ms[4] = {-1.f, -1.f, -1.f, -1.f};
-	double stage_total_ms[4] = {0, 0, 0, 0};
-	long long stage_count[4] = {0, 0, 0, 0};
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[kStages];
+	float stage_ms[kStages] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+	double stage_total_ms[kStages] = {0, 0, 0, 0, 0};
+	long long stage_count[kStages] = {0, 0, 0, 0, 0};
 
 	void set_error(const std::string &s) { err = s; }
 	~mvdb_index()
@@ -384,6 +390,7 @@ struct mvdb_index {
 		(void)hipFree(f32_dev);
 		if (f32_pinned) (void)hipHostFree(f32_pinned);
 		if (err_host) (void)hipHostFree(err_host);
+		if (lean_stats_host) (void)hipHostFree(lean_stats_host);
 		for (auto &s : hs) {
 			if (s.stream) {
 				(void)hipStreamSynchronize(s.stream);
@@ -443,6 +450,13 @@ int ensure_device(mvdb_index *h)
 		void *dp = nullptr;
 		HIP_OK(h, hipHostGetDevicePointer(&dp, h->err_host, 0));
 		h->err_dev = static_cast<int *>(dp);
+	}
+	if (!h->lean_stats_host) {
+		HIP_OK(h, hipHostMalloc(reinterpret_cast<void **>(&h->lean_stats_host), 64, hipHostMallocMapped));
+		std::memset(h->lean_stats_host, 0, 64);
+		void *dp = nullptr;
+		HIP_OK(h, hipHostGetDevicePointer(&dp, h->lean_stats_host, 0));
+		h->lean_stats_dev = static_cast<int *>(dp);
 	}
 	return 1;
 }
@@ -553,6 +567,57 @@ int launch_traverse_duo_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipS
 	return launch_traverse_duo_w<J, FULL, 3>(h, a, lds, s);
 }
 
+template <int J, bool FULL>
+int launch_traverse_lean_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
+{
+	static int mark[16] = {0};
+	if (!set_max_lds(h, reinterpret_cast<const void *>(&traverse_lean_kernel<J, FULL>), mark, lds)) return 0;
+	hipLaunchKernelGGL((traverse_lean_kernel<J, FULL>), dim3(a.nq), dim3(64), lds, s, a);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+int launch_traverse_lean(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
+{
+	const size_t lds = traverse_lean_lds_bytes(a.ef, a.cand_cap);
+	const int stride = a.ix.row_stride;
+	const int J = (stride + 127) / 128;
+	const bool full = stride == J * 128;
+#define MVDB_L(JJ)                                                                      \
+	if (J <= JJ) {                                                                      \
+		if (full && J == JJ) return launch_traverse_lean_t<JJ, true>(h, a, lds, s);     \
+		return launch_traverse_lean_t<JJ, false>(h, a, lds, s);                         \
+	}
+	MVDB_L(1)
+	MVDB_L(2)
+	MVDB_L(3)
+	MVDB_L(4)
+	MVDB_L(6)
+	MVDB_L(8)
+#undef MVDB_L
+	h->set_error("dim > 1024 is not supported by the traversal kernel");
+	return 0;
+}
+
+int launch_replay(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
+{
+	// the sort needs staging for the popped entries; a launch in which no query can be cut off skips it
+	const bool may_sort = !(a.set_only && a.ef <= a.k && a.ef <= a.results_cap);
+	const size_t lds = replay_lds_bytes(a.ef, may_sort);
+	static int mark[16] = {0};
+	if (!set_max_lds(h, reinterpret_cast<const void *>(&replay_kernel), mark, lds)) return 0;
+	hipLaunchKernelGGL(replay_kernel, dim3(a.nq), dim3(64), lds, s, a, may_sort ? 1 : 0);
+	HIP_OK(h, hipGetLastError());
+	return 1;
+}
+
+// The lean path (one wave per query, result heap replayed afterwards) whenever a neighbour list fits one 64-lane
+// chunk; mvdb_set_tuning(h, 1..3, ..) selects the kernels that keep the result heap inside the traversal.
+bool traverse_use_lean(const mvdb_index *h, const TraverseArgs &a)
+{
+	return a.ix.m0 <= kLeanMaxM0 && (h->traverse_waves == 0 || h->traverse_waves == 4);
+}
+
 // Several waves per query (traverse_duo.hip.hpp: three by default, mvdb_set_tuning(h, 2, ..) for the
 // two-wave variant) whenever a neighbour list fits one 64-lane chunk; mvdb_set_tuning(h, 1, ..)
 // selects the one-wave kernel for A/B timing.
@@ -561,9 +626,9 @@ bool traverse_use_duo(const mvdb_index *h, const TraverseArgs &a)
 	return a.ix.m0 <= kDuoMaxM0 && h->traverse_waves != 1;
 }
 
-int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
+int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s, bool one_wave = false)
 {
-	const bool duo = traverse_use_duo(h, a);
+	const bool duo = !one_wave && traverse_use_duo(h, a);
 	const size_t lds = duo ? traverse_duo_lds_bytes(a.ef, a.cand_cap) : traverse_lds_bytes(a.ef, a.cand_cap);
 	const int stride = a.ix.row_stride;
 	const int J = (stride + 127) / 128;
@@ -1007,6 +1072,11 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	a.epoch = 1;
 	a.vis_log = nullptr;  // memset mode unless the caller sets a log up
 	a.vis_log_cap = 0;
+	a.adm_log = nullptr;  // lean path only (search_many_dev_impl)
+	a.adm_log_cap = 0;
+	a.adm_n = a.flag = a.lean_stats = nullptr;
+	a.only_flagged = nullptr;
+	a.prof = nullptr;
 }
 
 mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
@@ -1058,13 +1128,32 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		return 0;
 	}
 	// bitmap clean-up: per-launch memset, or the kernel's own log-and-clear (VisitedLog) for large indexes
-	const bool log_mode = !MVDB_VISITED_STAMPS && h->visited_mode == 2;
+	const bool lean = traverse_use_lean(h, a);  // the lean kernel always works on a bitmap the launcher zeroed
+	const bool log_mode = !MVDB_VISITED_STAMPS && h->visited_mode == 2 && !lean;
 	a.vis_log = nullptr;
 	a.vis_log_cap = h->visited_log_cap > 0 ? h->visited_log_cap : kVisitedLogCap;
 	if (log_mode) {
 		a.vis_log = static_cast<uint32_t *>(sc->vis_log.need((size_t)slab * (size_t)a.vis_log_cap * 4));
 		if (!a.vis_log) {
 			h->set_error("out of device memory (visited logs)");
+			return 0;
+		}
+	}
+	// lean path: the traversal logs its admissions, replay_kernel rebuilds the result heap from the log
+	a.adm_log = nullptr;
+	a.adm_log_cap = 0;
+	a.adm_n = a.flag = nullptr;
+	a.lean_stats = h->lean_stats_dev;
+	a.only_flagged = nullptr;
+	if (lean) {
+		a.adm_log_cap = h->lean_log_cap > 0 ? h->lean_log_cap : 12 * a.ef + 1024;
+		const size_t per_q = (size_t)a.adm_log_cap * sizeof(uint2);
+		slab = (int)std::min<size_t>((size_t)slab, std::max<size_t>(1, ((size_t)2 << 30) / per_q));  // <= 2 GiB of logs per stream
+		a.adm_log = static_cast<uint2 *>(sc->adm_log.need((size_t)slab * per_q));
+		a.adm_n = static_cast<int *>(sc->adm_n.need((size_t)slab * 4));
+		a.flag = static_cast<int *>(sc->flag.need((size_t)slab * 4));
+		if (!a.adm_log || !a.adm_n || !a.flag) {
+			h->set_error("out of device memory (admission logs)");
 			return 0;
 		}
 	}
@@ -1089,7 +1178,6 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 			sc->vis_clean = false;  // the launch leaves its marks behind
 		}
 		a.epoch = ++sc->vis_epoch;
-		StageTimer t(h, 1, s);  // brackets the traversal kernel only
 		a.q = d_q + (size_t)q0 * g.cfg.dim;
 		a.nq = n;
 		a.visited = vis;
@@ -1103,7 +1191,23 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 #ifdef MVDB_TRAVERSE_PROFILE
 		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * kProfSlots * 8)) + (size_t)q0 * kProfSlots;
 #endif
-		if (!launch_traverse(h, a, s)) return 0;
+		if (lean) {
+			{
+				StageTimer t(h, 1, s);  // brackets the traversal kernel only
+				if (!launch_traverse_lean(h, a, s)) return 0;
+			}
+			StageTimer t(h, 4, s);
+			// queries the lean kernel gave up on (a distance beyond 16 bits, a full log): the one-wave kernel with the
+			// result heap inside, on the bitmaps those queries left clean; every other workgroup leaves at once
+			TraverseArgs fb = a;
+			fb.only_flagged = a.flag;
+			fb.vis_log = nullptr;
+			if (!launch_traverse(h, fb, s, true)) return 0;
+			if (!launch_replay(h, a, s)) return 0;
+		} else {
+			StageTimer t(h, 1, s);
+			if (!launch_traverse(h, a, s, false)) return 0;
+		}
 	}
 	return 1;
 }
@@ -1700,8 +1804,8 @@ int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 #endif
 int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)
 {
-	if (traverse_waves < 0 || traverse_waves > 3 || (rerank_waves != 0 && rerank_waves != 2 && rerank_waves != 4)) {
-		h->set_error("mvdb_set_tuning: traverse_waves must be 0..3, rerank_waves 0, 2 or 4");
+	if (traverse_waves < 0 || traverse_waves > 4 || (rerank_waves != 0 && rerank_waves != 2 && rerank_waves != 4)) {
+		h->set_error("mvdb_set_tuning: traverse_waves must be 0..4, rerank_waves 0, 2 or 4");
 		return 0;
 	}
 	h->traverse_waves = traverse_waves;
@@ -1731,6 +1835,13 @@ void mvdb_upload_counters(const mvdb_index *h, long long *out3)
 
 void mvdb_debug_inject_abort(mvdb_index *h, int query) { h->inject_abort_q = query; }
 void mvdb_debug_inject_build_failure(mvdb_index *h, int pass) { h->inject_build_fail_pass = pass; }
+void mvdb_debug_set_lean_log_cap(mvdb_index *h, int cap) { h->lean_log_cap = cap > 0 ? cap : 0; }
+
+void mvdb_lean_fallbacks(const mvdb_index *h, long long *out3)
+{
+	for (int i = 0; i < 3; i++)
+		out3[i] = h->lean_stats_host ? (long long)__atomic_load_n(h->lean_stats_host + 1 + i, __ATOMIC_RELAXED) : 0;
+}
 
 int mvdb_release_stream(mvdb_index *h, void *stream)
 {
@@ -1748,13 +1859,13 @@ int mvdb_release_stream(mvdb_index *h, void *stream)
 void mvdb_enable_timing(mvdb_index *h, int on) { h->timing = on != 0; }
 float mvdb_last_stage_ms(mvdb_index *h, int stage)
 {
-	if (stage < 0 || stage > 3) return -1.f;
+	if (stage < 0 || stage >= kStages) return -1.f;
 	resolve_stage(h, stage);
 	return h->stage_ms[stage];
 }
 int mvdb_stage_stats(mvdb_index *h, int stage, long long *launches, double *total_ms, int reset)
 {
-	if (stage < 0 || stage > 3) return 0;
+	if (stage < 0 || stage >= kStages) return 0;
 	resolve_stage(h, stage);
 	if (launches) *launches = h->stage_count[stage];
 	if (total_ms) *total_ms = h->stage_total_ms[stage];

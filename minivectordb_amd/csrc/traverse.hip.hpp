@@ -446,6 +446,13 @@ struct TraverseArgs {
 	unsigned long long *prof;  // diagnostic builds only (MVDB_TRAVERSE_PROFILE): nq x 16 cycle sums
 	int *err;             // device-visible error word of the handle (host-pinned): bit 0 = a query aborted
 	int inject_abort_q;   // test hook (mvdb_debug_inject_abort): this query takes the abort path; -1 = none
+	// traverse_lean.hip.hpp: the admitted (key, id) pairs of every query in admission order, for replay_kernel
+	uint2 *adm_log;       // nq x adm_log_cap
+	int adm_log_cap;
+	int *adm_n;           // nq: entries logged
+	int *flag;            // nq: kLeanDone, or why the query is left to traverse_kernel
+	int *lean_stats;      // device-mapped host counters of the handle, indexed by flag value, or null
+	const int *only_flagged;  // traverse_kernel as the fall-back of the lean path: only queries flagged 1..3 run
 };
 
 // An aborted query (traverse_duo's bounded waits, or the test hook) is reported three ways: out_count = -1,
@@ -498,6 +505,10 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 	const int lane = threadIdx.x;
 	const int qi = blockIdx.x;
 	if (qi >= a.nq) return;
+	if (a.only_flagged) {  // fall-back launch behind traverse_lean_kernel
+		const int f = rfl(a.only_flagged[qi]);
+		if (f < 1 || f > 3) return;
+	}
 	const DevIndexView &ix = a.ix;
 	if (qi == a.inject_abort_q) {  // test hook: the one-wave kernel has no abort path of its own
 		traverse_report_abort(a, qi, lane);

@@ -1,0 +1,781 @@
+// traverse_lean.hip.hpp -- layer-0 search with the RESULT HEAP TAKEN OUT of the traversal: one wave per query.
+//
+// Same algorithm as traverse.hip.hpp (search() + search_layer(), assembly/hnsw.ts:960-1027, :423-523), same
+// candidate lists bit for bit.  What changed is where the reference's two heaps live:
+//
+//  * Every DECISION search_layer takes from the result heap -- admit iff `res_size < ef || d < worst`
+//    (:499), the new `worst` after a replace_root (:506-507), the termination test (:466) -- depends only on
+//    the MULTISET of result keys, never on how the heap array arranges them.  The kernel therefore keeps the
+//    keys only: the largest ones sorted in registers (KeyWin: up to 64 distinct key values with their
+//    multiplicities, one per lane), the rest as a flat unsorted u16 array in LDS (2 bytes per result).  Admitting
+//    a neighbour is "drop the largest key, insert the new one": a lane shift, no sift-down.  When the window runs
+//    empty it is refilled from the flat array (histogram pass -> threshold -> the keys above it move over).
+//  * The ARRAY the reference would hold at the end (which of several equal keys was evicted, the order of the
+//    returned list) is reproduced afterwards by replay_kernel: the traversal logs the admitted (key, id) pairs in
+//    admission order, the replay runs res_push / res_replace_root / res_to_sorted_full (:233-325) over that
+//    log on a real array heap in LDS.  Same operations in the same order as the reference => the same array.
+//    It is pure LDS work, runs as its own launch after the traversal and overlaps the next batch's traversal.
+//  * The candidate min-heap (:141-213) stays an exact array heap (its pop order and the pushes dropped at
+//    cand_cap, :500, decide which nodes are expanded), but as 16-bit keys + 32-bit ids in separate arrays:
+//    6 bytes per entry instead of 8.
+//  With the 9.6 KB result heap gone and the smaller entries a balanced query (ef 1200, cand_cap 2432) needs
+//  ~18 KB of LDS instead of 30 KB and ONE wave instead of three: 8 queries per CU instead of 5, and no mailboxes,
+//  no polling, no abort protocol.
+//
+// One wave does everything, software-pipelined: the candidate-heap work of expansion e (the pushes list e-1
+// admitted, then the pop of candidate e) runs in the shadow of expansion e's row gather.  That needs candidate
+// e's identity before those pushes have happened, and it is known exactly: the root after the pushes is the
+// first-pushed minimum of the admitted neighbours if that is strictly below the root the last pop left (a
+// sift-up passes a parent only when strictly smaller, :163), else that root.  The pop re-checks it.
+//
+// 16-bit keys: distances are exact integers; a query whose walk meets a distance above 65535 (impossible for
+// quantised unit vectors: d <= (127+127)^2 = 64516) gives up, leaves its visited bitmap clean and is flagged
+// for traverse_kernel, which the launcher runs for flagged queries only.  So does a query whose log overflows.
+#pragma once
+
+#include "traverse.hip.hpp"
+
+namespace mvdb {
+
+constexpr int kLeanMaxM0 = 64;            // one 64-lane chunk per neighbour list
+constexpr unsigned kLeanKeyMax = 65535u;  // 16-bit keys
+constexpr unsigned kLeanInf = 0xffffffffu;
+constexpr int kLeanTake = 48;             // a refill moves at most this many entries into the window (16 lanes of headroom)
+
+// flag[qi] after traverse_lean_kernel: what still has to happen to the query
+enum : int {
+	kLeanDone = 0,      // log written: replay_kernel produces the output
+	kLeanBigKey = 1,    // a distance above 65535: traverse_kernel takes the query
+	kLeanLogFull = 2,   // more admissions than the log holds: traverse_kernel takes the query
+	kLeanMismatch = 3,  // the popped root was not the predicted candidate (never observed): traverse_kernel takes the query
+	kLeanAborted = 4,   // test hook (mvdb_debug_inject_abort): reported as an aborted query
+};
+
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+__device__ __forceinline__ unsigned lds_r16(unsigned a) { return *reinterpret_cast<const lds_u16 *>((size_t)a); }
+__device__ __forceinline__ void lds_w16(unsigned a, unsigned v) { *reinterpret_cast<lds_u16 *>((size_t)a) = (unsigned short)v; }
+__device__ __forceinline__ unsigned lds_r32(unsigned a) { return *reinterpret_cast<const lds_u32 *>((size_t)a); }
+__device__ __forceinline__ void lds_w32(unsigned a, unsigned v) { *reinterpret_cast<lds_u32 *>((size_t)a) = v; }
+
+__device__ __forceinline__ unsigned lean_readlane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned long long lean_lt_mask(int lane) { return (1ull << lane) - 1; }
+
+// minimum / maximum over the wave as a uniform value (DPP within rows of 16, then 4 readlanes)
+__device__ __forceinline__ unsigned lean_wave_min(unsigned x)
+{
+	auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+	return mn(mn(lean_readlane(x, 0), lean_readlane(x, 16)), mn(lean_readlane(x, 32), lean_readlane(x, 48)));
+}
+__device__ __forceinline__ unsigned lean_wave_max(unsigned x)
+{
+	auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+	x = mx(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+	x = mx(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+	x = mx(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+	x = mx(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+	return mx(mx(lean_readlane(x, 0), lean_readlane(x, 16)), mx(lean_readlane(x, 32), lean_readlane(x, 48)));
+}
+// whole-wave shift by one lane (DPP wave_shr:1)
+__device__ __forceinline__ unsigned lean_shr1(unsigned x, unsigned fill)  // lane l <- lane l-1, lane 0 <- fill
+{
+	return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
+}
+
+// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | low keys u16[ef+64] | 4 x 64 dwords of buffers
+struct LeanCarve {
+	unsigned ck, ci, lowk, buf;
+	size_t total;
+};
+__host__ __device__ inline LeanCarve lean_carve(int ef, int cand_cap)
+{
+	LeanCarve c;
+	unsigned o = 0;
+	c.ck = o;
+	o += ((unsigned)(cand_cap + 2) * 2u + 15u) & ~15u;
+	c.ci = o;
+	o += ((unsigned)(cand_cap + 2) * 4u + 15u) & ~15u;
+	c.lowk = o;
+	o += ((unsigned)(ef + 64) * 2u + 15u) & ~15u;
+	c.buf = o;
+	o += 4u * 64u * 4u;
+	c.total = o;
+	return c;
+}
+__host__ __device__ inline size_t traverse_lean_lds_bytes(int ef, int cand_cap) { return lean_carve(ef, cand_cap).total; }
+
+// ---- candidate min-heap (hnsw.ts:141-213), 1-based, keys u16[] and ids u32[] apart ---------------------
+struct LeanCand {
+	unsigned kb, ib;  // LDS byte offsets of key[0], id[0]
+
+	__device__ __forceinline__ unsigned key_at(int p) const { return lds_r16(kb + 2u * (unsigned)p); }
+	__device__ __forceinline__ unsigned id_at(int p) const { return lds_r32(ib + 4u * (unsigned)p); }
+	// cand_push (:153-171): one parallel sift-up.  Lane j looks at ancestor j+1 of the new slot; ancestors below
+	// the stopping one (:163 parent <= child stops) move down a level.  Idle lanes rewrite entry 0 (unused).
+	__device__ __forceinline__ void push(int size, unsigned nid, unsigned nkey, int lane) const
+	{
+		const unsigned pos = (unsigned)size + 1u;
+		const unsigned sh = lane < 31 ? (unsigned)lane : 31u;
+		const unsigned self = pos >> sh, anc = self >> 1;
+		const unsigned ek = lds_r16(kb + 2u * anc), ei = lds_r32(ib + 4u * anc);
+		const bool stop = anc == 0u || ek <= nkey;
+		const int Jn = __builtin_ctzll(__ballot(stop));
+		const unsigned dst = lane <= Jn ? self : 0u;
+		lds_w16(kb + 2u * dst, lane == Jn ? nkey : ek);
+		lds_w32(ib + 4u * dst, lane == Jn ? nid : ei);
+	}
+	// the sift-down of cand_pop (:191-210) for (nid, nkey) entering at the root of a heap of `size`, five levels
+	// per LDS round trip (LdsHeap::sift_from_wide on the split arrays): lane j holds node j + 2 of the subtree
+	// under p in heap numbering, every node decides whether it is the child its parent would pick (:201 the right
+	// one only if strictly smaller) and whether the walk goes on through it (:206), the path is followed on the
+	// scalar unit through one ballot, and the entries on the path move up together.
+	__device__ __forceinline__ void sift_root(int size, unsigned nid, unsigned nkey, int lane) const
+	{
+		int p = 1;
+		const int li = lane + 2;
+		const int d = 31 - __builtin_clz(li);  // 1..5 (6 in the two spare lanes)
+		const int off = li - (1 << d);
+		for (;;) {
+			if (2 * p > size) break;  // a leaf
+			const int pos = (p << d) + off;
+			const bool valid = lane < 62 && pos <= size;
+			const unsigned slot = valid ? (unsigned)pos : 0u;
+			unsigned ek = lds_r16(kb + 2u * slot);
+			const unsigned ei = lds_r32(ib + 4u * slot);
+			ek = valid ? ek : kLeanInf;
+			const unsigned ks = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ek, 0xB1, 0xf, 0xf, false);  // sibling
+			const bool chosen = (lane & 1) ? ek < ks : ek <= ks;
+			const unsigned long long cont = __ballot(chosen && nkey > ek);
+			unsigned long long path = 0;
+			int cur = 1, steps = 0;
+			for (; steps < 5; steps++) {
+				const unsigned pair = (unsigned)(cont >> (2 * cur - 2)) & 3u;  // at most one bit: one child is chosen
+				if (!pair) break;
+				cur = 2 * cur + (int)(pair >> 1);
+				path |= 1ull << (cur - 2);
+			}
+			if ((path >> lane) & 1ull) {
+				lds_w16(kb + 2u * (unsigned)(pos >> 1), ek);
+				lds_w32(ib + 4u * (unsigned)(pos >> 1), ei);
+			}
+			const int dc = 31 - __builtin_clz(cur);
+			p = (p << dc) + (cur - (1 << dc));
+			if (steps < 5) break;
+		}
+		if (lane == 0) {
+			lds_w16(kb + 2u * (unsigned)p, nkey);
+			lds_w32(ib + 4u * (unsigned)p, nid);
+		}
+	}
+};
+
+// ---- the largest result keys, sorted in registers ---------------------------------------------------------
+// Lanes 0..V-1 hold DISTINCT key values in ascending order with their multiplicities.  Invariant: every key
+// of the result multiset that is >= T sits here; everything below T is in the flat LDS array.
+struct KeyWin {
+	unsigned wk = 0, wc = 0;
+	int V = 0;
+	unsigned T = kLeanInf;
+	__device__ __forceinline__ unsigned worst() const { return lean_readlane(wk, V - 1); }
+	__device__ __forceinline__ void remove_max(int lane)
+	{
+		const unsigned c = lean_readlane(wc, V - 1);
+		if (c > 1u) {
+			if (lane == V - 1) wc -= 1u;
+		} else {
+			V -= 1;
+		}
+	}
+};
+
+// distances of rows ids_s[0..n) -> dist_s[0..n) as exact integers; `big` collects "above 65535" per lane
+template <int J, bool FULL>
+__device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const QueryRegs<J> &Q, const int *ids_s, unsigned *dist_s,
+                                               int n, int safe_row, int lane, bool &big)
+{
+	const int g = lane >> 3, s = lane & 7;
+	for (int p0 = 0; p0 < n; p0 += 32) {
+		int4 v[4][J];
+		int slot[4];
+#pragma unroll
+		for (int pp = 0; pp < 4; pp++) {
+			slot[pp] = p0 + pp * 8 + g;
+			const int rid = slot[pp] < n ? ids_s[slot[pp]] : safe_row;
+			if (p0 + pp * 8 < n) load_row<J, FULL>(v[pp], ix, rid, s);
+		}
+#pragma unroll
+		for (int pp = 0; pp < 4; pp++) {
+			if (p0 + pp * 8 < n) {
+				const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v[pp])));
+				if (slot[pp] < n) big = big || tot > kLeanKeyMax;
+				if (s == 0 && slot[pp] < n) dist_s[slot[pp]] = tot;
+			}
+		}
+	}
+}
+
+// diagnostic stamps (MVDB_TRAVERSE_PROFILE builds only), slots: 0 query + descent, 1 list + issue of the memory
+// phase, 2 candidate-heap work in the shadow of the loads, 3 rows + distances, 4 visited test + compaction,
+// 5 admission (6 = the refills inside it), 7 log + prediction; counters: 8 lists not prefetched, 9 admitted
+// neighbours, 10 refills, 11 of them dense, 12 expansions whose next candidate came out of the list itself
+#ifdef MVDB_TRAVERSE_PROFILE
+#define MVDB_LEAN_COUNT(slot, v) prof_acc[slot] += (unsigned long long)(v)
+#else
+#define MVDB_LEAN_COUNT(slot, v) \
+	do {                         \
+	} while (0)
+#endif
+
+template <int J, bool FULL>
+__global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const int lane = threadIdx.x;
+	const int qi = blockIdx.x;
+	if (qi >= a.nq) return;
+	const DevIndexView &ix = a.ix;
+	if (qi == a.inject_abort_q) {  // test hook
+		if (lane == 0) a.flag[qi] = kLeanAborted;
+		traverse_report_abort(a, qi, lane);
+		return;
+	}
+#ifdef MVDB_TRAVERSE_PROFILE
+	unsigned long long prof_acc[16] = {};
+	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
+
+	const int ef = a.ef, cand_cap = a.cand_cap, m0 = ix.m0;
+	const LeanCarve cv = lean_carve(ef, cand_cap);
+	const unsigned lds0 = (unsigned)(size_t)lds_raw;
+	const LeanCand cand{lds0 + cv.ck, lds0 + cv.ci};
+	const unsigned lowk = lds0 + cv.lowk;
+	int *all_ids = reinterpret_cast<int *>(lds_raw + cv.buf);
+	unsigned *all_dist = reinterpret_cast<unsigned *>(all_ids + 64);
+	int *buf_a = reinterpret_cast<int *>(all_dist + 64);      // compacted ids | descent codes | refill histogram
+	unsigned *buf_b = reinterpret_cast<unsigned *>(buf_a + 64);  // compacted distances | refill staging
+	const unsigned hist = lds0 + cv.buf + 512u, stage = lds0 + cv.buf + 768u;
+
+	QueryRegs<J> Q;
+	load_query<J>(Q, a.q + (size_t)qi * (size_t)ix.dim, ix.dim, lane);
+	int n_dist = 0, n_l0 = 0, n_up = 0;
+	bool big = false;  // some distance does not fit 16 bits
+	bool touched = false;  // the visited bitmap holds bits of this query
+	int bail = -1;
+
+	// search(): hnsw.ts:961-969 (entry validity is established by the host before launch)
+	int cur = ix.entry, cur_code = ix.entry_code;
+	unsigned cur_d;
+	{
+		if (lane == 0) all_ids[0] = cur;
+		lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, 1, cur, lane, big);
+		cur_d = (unsigned)rfl((int)all_dist[0]);
+		n_dist++;
+	}
+	// upper-layer greedy descent, :971-1004 (integer distances order like the reference's f32 values below 2^24)
+	for (int l = ix.max_level; l > 0; l--) {
+		bool changed = true;
+		while (changed) {
+			changed = false;
+			n_up++;
+			const int lvl = cur_code & 3, cum = cur_code >> 2;
+			if (lvl < l) continue;  // no list on this layer (corrupt graph): treated as empty
+			const int2 *lst = ix.upper + (size_t)(cum + l - 1) * (size_t)ix.m;
+			for (int base = 0; base < ix.m; base += 64) {
+				int2 en = make_int2(-1, -1);
+				if (base + lane < ix.m) en = lst[base + lane];
+				const int n = __builtin_popcountll(__ballot(en.x >= 0));  // canonical lists: valid entries are a prefix
+				if (n == 0) break;
+				if (en.x >= 0) {
+					all_ids[lane] = en.x;
+					buf_a[lane] = en.y;
+				}
+				lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, n, cur, lane, big);
+				n_dist += n;
+				// sequential scan with strict `<` == first occurrence of the minimum, if below cur_d
+				const unsigned my = lane < n ? all_dist[lane] : kLeanInf;
+				const unsigned d = lean_wave_min(my);
+				if (d < cur_d) {  // :997-1001
+					const int idx = __builtin_ctzll(__ballot(my == d));
+					cur_d = d;
+					cur = rfl(all_ids[idx]);
+					cur_code = rfl(buf_a[idx]);
+					changed = true;
+				}
+			}
+		}
+	}
+	if (__ballot(big)) bail = kLeanBigKey;
+	MVDB_STAMP(0);
+
+	// ---------------- search_layer(query, cur, 0, ef, false): :423-523 ----------------
+	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride), a.epoch};
+	uint2 *log = a.adm_log + (size_t)qi * (size_t)a.adm_log_cap;
+	int cand_size = 0, res_size = 0, low_n = 0, n_adm = 0, s_hint = 0;
+	unsigned worst = kLeanInf;  // max of the result keys; consulted only once res_size >= ef
+	unsigned low_max = 0;       // max of the flat array (exact whenever a refill may need it)
+	unsigned fill_max = 0;      // per lane: keys appended while the result set was filling
+	KeyWin win;
+
+	auto low_append1 = [&](unsigned d) {
+		if (lane == 0) lds_w16(lowk + 2u * (unsigned)low_n, d);
+		low_n++;
+		low_max = low_max > d ? low_max : d;
+	};
+	// window empty, flat array not: move the largest keys of the flat array into the window
+	auto refill = [&]() {
+#ifdef MVDB_TRAVERSE_PROFILE
+		const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+		const unsigned Kmax = low_max;
+		int s = s_hint, L = 0, acc = 0;
+		unsigned Tn = 0, hc = 0;
+		for (;;) {
+			// histogram of the keys just below Kmax, bins of 2^s key values, bin 0 on top
+			lds_w32(hist + 4u * (unsigned)lane, 0u);
+			for (int i0 = 0; i0 < low_n; i0 += 64) {
+				const int i = i0 + lane;
+				if (i < low_n) {
+					const unsigned b = (Kmax - lds_r16(lowk + 2u * (unsigned)i)) >> s;
+					if (b < 64u)
+						__hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)(hist + 4u * b)), 1u, __ATOMIC_RELAXED,
+						                       __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+			hc = lds_r32(hist + 4u * (unsigned)lane);
+			if (s == 0) {  // a bin is a key value: the bins ARE the window, any multiplicity
+				Tn = Kmax >= 63u ? Kmax - 63u : 0u;
+				break;
+			}
+			L = 0;
+			acc = 0;
+			for (; L < 64; L++) {  // the largest prefix of bins holding <= kLeanTake entries
+				const int c = (int)lean_readlane(hc, L);
+				if (acc + c > kLeanTake) break;
+				acc += c;
+			}
+			if (L > 0) {
+				const unsigned span = (unsigned)L << s;
+				Tn = Kmax + 1u > span ? Kmax + 1u - span : 0u;
+				break;
+			}
+			s = s > 3 ? s - 3 : 0;  // the top bin alone is too crowded: finer bins
+		}
+		const bool dense = s == 0;
+		// keys >= Tn leave the flat array (compacted in place; its order carries no meaning)
+		int newn = 0, cpos = 0;
+		unsigned rmax = 0;
+		for (int i0 = 0; i0 < low_n; i0 += 64) {
+			const int i = i0 + lane;
+			const bool valid = i < low_n;
+			const unsigned k = valid ? lds_r16(lowk + 2u * (unsigned)i) : 0u;
+			const bool take = valid && k >= Tn;
+			const bool keep = valid && !take;
+			if (!dense) {
+				const unsigned long long tm = __ballot(take);
+				if (take) lds_w32(stage + 4u * (unsigned)(cpos + __builtin_popcountll(tm & lean_lt_mask(lane))), k);
+				cpos += __builtin_popcountll(tm);
+			}
+			const unsigned long long km = __ballot(keep);
+			if (keep) lds_w16(lowk + 2u * (unsigned)(newn + __builtin_popcountll(km & lean_lt_mask(lane))), k);
+			newn += __builtin_popcountll(km);
+			rmax = keep && k > rmax ? k : rmax;
+		}
+		const int taken = low_n - newn;
+		low_n = newn;
+		low_max = lean_wave_max(rmax);
+		if (dense) {
+			const unsigned long long nz = __ballot(hc != 0u);
+			const unsigned long long above = lane == 63 ? 0ull : (nz >> (lane + 1));  // bins below this key value
+			if (hc != 0u) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(above), ((Kmax - (unsigned)lane) & 0xffffu) | (hc << 16));
+			const unsigned v = lds_r32(stage + 4u * (unsigned)lane);
+			win.wk = v & 0xffffu;
+			win.wc = v >> 16;
+			win.V = __builtin_popcountll(nz);
+			s_hint = taken < 12 ? 2 : 0;
+		} else {
+			const int cnt = cpos;  // <= kLeanTake
+			const unsigned key = lane < cnt ? lds_r32(stage + 4u * (unsigned)lane) : kLeanInf;
+			unsigned lt = 0, eqb = 0;  // rank by counting
+			for (int j = 0; j < cnt; j++) {
+				const unsigned kj = lean_readlane(key, j);
+				lt += kj < key ? 1u : 0u;
+				eqb += (kj == key && j < lane) ? 1u : 0u;
+			}
+			if (lane < cnt) lds_w32(hist + 4u * (lt + eqb), key);
+			const unsigned sk = lane < cnt ? lds_r32(hist + 4u * (unsigned)lane) : kLeanInf;
+			const unsigned prev = lean_shr1(sk, kLeanInf);
+			const bool head = lane < cnt && (lane == 0 || sk != prev);
+			const unsigned long long hm = __ballot(head);
+			const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+			const int next = above ? lane + 1 + __builtin_ctzll(above) : cnt;
+			if (head) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(hm & lean_lt_mask(lane)), sk | ((unsigned)(next - lane) << 16));
+			const unsigned v = lds_r32(stage + 4u * (unsigned)lane);
+			win.wk = v & 0xffffu;
+			win.wc = v >> 16;
+			win.V = __builtin_popcountll(hm);
+			s_hint = (L == 64 && acc < 24) ? (s < 10 ? s + 1 : 10) : (L < 6 ? s - 1 : s);
+		}
+		win.T = Tn;
+		MVDB_LEAN_COUNT(10, 1);
+		MVDB_LEAN_COUNT(11, dense ? 1 : 0);
+#ifdef MVDB_TRAVERSE_PROFILE
+		prof_acc[6] += __builtin_amdgcn_s_memtime() - t0_;
+#endif
+	};
+	// d >= win.T joins the window
+	auto win_insert = [&](unsigned d) {
+		const bool valid = lane < win.V;
+		const unsigned long long eq = __ballot(valid && win.wk == d);
+		if (eq) {
+			if (lane == __builtin_ctzll(eq)) win.wc += 1u;
+			return;
+		}
+		// A free lane always exists: a sparse refill brings at most kLeanTake entries and the number of entries at or
+		// above T never grows (every admission removes one of them), a dense window spans 64 key values.
+		if (win.V == 64) {
+			bail = kLeanMismatch;
+			return;
+		}
+		const int r = __builtin_popcountll(__ballot(lane < win.V && win.wk < d));
+		const unsigned sk = lean_shr1(win.wk, 0u), sc = lean_shr1(win.wc, 0u);
+		if (lane > r) {
+			win.wk = sk;
+			win.wc = sc;
+		}
+		if (lane == r) {
+			win.wk = d;
+			win.wc = 1u;
+		}
+		win.V += 1;
+	};
+	// admission of a list in list order (:499-508) on the key multiset; returns the admitted lanes.  Logs them.
+	auto admit_list = [&](int n, unsigned my_d, int my_id) -> unsigned long long {
+		unsigned long long adm = 0, rem = n >= 64 ? ~0ull : ((1ull << n) - 1);
+		if (res_size < ef) {  // :504-505 while the result set fills up everything is admitted
+			const int f = n < ef - res_size ? n : ef - res_size;
+			if (lane < f) {
+				lds_w16(lowk + 2u * (unsigned)(low_n + lane), my_d);
+				fill_max = fill_max > my_d ? fill_max : my_d;
+			}
+			low_n += f;
+			res_size += f;
+			adm = f >= 64 ? ~0ull : ((1ull << f) - 1);
+			rem &= ~adm;
+			if (res_size >= ef) {
+				low_max = lean_wave_max(fill_max);
+				refill();
+				worst = win.worst();
+			}
+		}
+		while (rem) {  // full: `worst` only falls, so a neighbour rejected once stays rejected
+			const unsigned long long m = __ballot(my_d < worst) & rem;
+			if (!m) break;
+			const int t = __builtin_ctzll(m);
+			rem &= ~((2ull << t) - 1);
+			adm |= 1ull << t;
+			const unsigned d = lean_readlane(my_d, t);
+			win.remove_max(lane);  // :506-507 replace_root drops the largest key ...
+			if (d >= win.T) win_insert(d);  // ... and d joins the multiset
+			else low_append1(d);
+			if (bail >= 0) return adm;
+			if (win.V == 0) refill();
+			worst = win.worst();
+		}
+		const int na = __builtin_popcountll(adm);
+		MVDB_LEAN_COUNT(9, na);
+		if (n_adm + na > a.adm_log_cap) {
+			bail = kLeanLogFull;
+			return adm;
+		}
+		if ((adm >> lane) & 1ull) log[n_adm + __builtin_popcountll(adm & lean_lt_mask(lane))] = make_uint2(my_d, (unsigned)my_id);
+		n_adm += na;
+		return adm;
+	};
+
+	// the entry point (:450-454): dist0 re-evaluates the row the descent ended on (counted, not re-read)
+	n_dist++;
+	unsigned long long pend = 0;  // pushes waiting for the candidate heap: lanes of (p_d, p_id)
+	unsigned p_d = cur_d;
+	int p_id = cur;
+	int c_id = cur;  // the candidate to expand next, known before the heap has seen it
+	unsigned c_d = cur_d;
+	if (bail < 0) {
+		if (lane == 0) vis.mark(cur);  // :452
+		touched = true;
+		pend = admit_list(1, lane == 0 ? cur_d : kLeanInf, cur) & 1ull;  // :453-454
+	}
+	int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
+	int seen_listed = 0, seen_new = 0;  // decaying counts: rows with the visited test while at least half were new
+	int o_id = -1;
+	unsigned o_key = 0;
+
+	while (bail < 0) {
+		if (res_size >= ef && c_d > worst) break;  // :466 (strict >)
+		int nb = -1;
+		if (pref_id == c_id) nb = pref_nb;
+		else {
+			if (lane < m0) nb = ix.adj0[(size_t)c_id * (size_t)m0 + lane];
+			MVDB_LEAN_COUNT(8, 1);
+		}
+		const int cnt = __builtin_popcountll(__ballot(nb >= 0));  // canonical lists: valid prefix
+		// candidate-heap work of this expansion, placed under the loads: the pushes the previous list admitted
+		// (:500-502), then cand_pop of this candidate (:460) and the fetch of the list of the root it leaves
+		auto heap_work = [&]() {
+			MVDB_STAMP(1);
+			for (unsigned long long m = pend; m; m &= m - 1) {
+				const int t = __builtin_ctzll(m);
+				cand.push(cand_size++, (unsigned)__builtin_amdgcn_readlane(p_id, t), lean_readlane(p_d, t), lane);
+			}
+			pend = 0;
+			const unsigned rk = (unsigned)rfl((int)cand.key_at(1));
+			const int ri = rfl((int)cand.id_at(1));
+			if (cand_size <= 0 || ri != c_id || rk != c_d) {
+				bail = kLeanMismatch;
+				return;
+			}
+			cand_size--;
+			if (cand_size > 0) {
+				const unsigned lk = (unsigned)rfl((int)cand.key_at(cand_size + 1));
+				const unsigned li = (unsigned)rfl((int)cand.id_at(cand_size + 1));
+				cand.sift_root(cand_size, li, lk, lane);
+				o_key = (unsigned)rfl((int)cand.key_at(1));
+				o_id = rfl((int)cand.id_at(1));
+				if (pref_id != o_id) {  // needed next unless a new neighbour undercuts it
+					pref_id = o_id;
+					pref_nb = -1;
+					if (lane < m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)m0 + lane];
+				}
+			}
+			MVDB_STAMP(2);
+		};
+
+		int n = 0;
+		unsigned my_d = kLeanInf;
+		int my_id = -1;
+		if (cnt == 0) {
+			heap_work();
+		} else {
+			const unsigned old = nb >= 0 ? vis.probe(nb) : 0u;  // :494-495 visited test-and-set
+			if (2 * seen_new < seen_listed) {
+				// rows of the NEW neighbours only, after the visited words are back
+				heap_work();
+				const bool isnew = nb >= 0 && !vis.seen(old, nb);
+				const unsigned long long nm = __ballot(isnew);
+				n = __builtin_popcountll(nm);
+				seen_listed += cnt - (seen_listed >> 2);
+				seen_new += n - (seen_new >> 2);
+				MVDB_STAMP(4);
+				if (n > 0) {
+					if (isnew) buf_a[__builtin_popcountll(nm & lean_lt_mask(lane))] = nb;
+					lean_dist_rows<J, FULL>(ix, Q, buf_a, buf_b, n, c_id, lane, big);  // :497
+					my_d = lane < n ? buf_b[lane] : kLeanInf;
+					my_id = lane < n ? buf_a[lane] : -1;
+				}
+				MVDB_STAMP(3);
+			} else {
+				// rows of every listed neighbour together with the visited test (one memory round trip instead of
+				// two; most listed neighbours are new while the search is still spreading)
+				if (nb >= 0) all_ids[lane] = nb;
+				const int g = lane >> 3, sl = lane & 7;
+				// 32 rows per pass, all in flight at once; no loop around the passes (a loop makes the compiler
+				// drain vmcnt before every reuse of the row registers)
+				auto pass = [&](const int p0, const bool first) {
+					int4 v[4][J];
+					int slot[4];
+#pragma unroll
+					for (int pp = 0; pp < 4; pp++) {
+						slot[pp] = p0 + pp * 8 + g;
+						const int rid = slot[pp] < cnt ? all_ids[slot[pp]] : c_id;
+						if (p0 + pp * 8 < cnt) load_row<J, FULL>(v[pp], ix, rid, sl);
+					}
+					if (first) heap_work();
+#pragma unroll
+					for (int pp = 0; pp < 4; pp++) {
+						if (p0 + pp * 8 < cnt) {
+							const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v[pp])));
+							if (sl == 0 && slot[pp] < cnt) all_dist[slot[pp]] = tot;
+						}
+					}
+				};
+				pass(0, true);
+				if (cnt > 32) pass(32, false);
+				MVDB_STAMP(3);
+				const bool isnew = nb >= 0 && !vis.seen(old, nb);
+				const unsigned long long nm = __ballot(isnew);
+				n = __builtin_popcountll(nm);
+				seen_listed += cnt - (seen_listed >> 2);
+				seen_new += n - (seen_new >> 2);
+				if (isnew) {
+					const int pos = __builtin_popcountll(nm & lean_lt_mask(lane));
+					const unsigned dd = all_dist[lane];  // :497
+					big = big || dd > kLeanKeyMax;
+					buf_a[pos] = nb;
+					buf_b[pos] = dd;
+				}
+				my_d = lane < n ? buf_b[lane] : kLeanInf;
+				my_id = lane < n ? buf_a[lane] : -1;
+				MVDB_STAMP(4);
+			}
+		}
+		if (bail >= 0) break;
+		if (__ballot(big)) {
+			bail = kLeanBigKey;
+			break;
+		}
+		n_l0++;
+		n_dist += n;
+		const unsigned long long adm = n > 0 ? admit_list(n, my_d, my_id) : 0ull;
+		if (bail >= 0) break;
+		MVDB_STAMP(5);
+		// ---- who is popped next.  Of the admitted neighbours the first `room` are pushed (:500); after those pushes
+		// the root is the first-pushed minimum if it is strictly below the root the pop left (:163), else that root.
+		const int room = cand_cap - cand_size;
+		unsigned long long pushed = room > 0 ? adm : 0ull;
+		while (__builtin_popcountll(pushed) > room) pushed &= ~(1ull << (63 - __builtin_clzll(pushed)));
+		pend = pushed;
+		p_d = my_d;
+		p_id = my_id;
+		if (pushed) {
+			const unsigned pd = ((pushed >> lane) & 1ull) ? my_d : kLeanInf;
+			const unsigned dmin = lean_wave_min(pd);
+			if (cand_size == 0 || dmin < o_key) {
+				const int idx = __builtin_ctzll(__ballot(pd == dmin));  // first occurrence
+				c_d = dmin;
+				c_id = __builtin_amdgcn_readlane(my_id, idx);
+				MVDB_LEAN_COUNT(12, 1);
+			} else {
+				c_d = o_key;
+				c_id = o_id;
+			}
+		} else {
+			if (cand_size == 0) break;  // :459 the heap is empty
+			c_d = o_key;
+			c_id = o_id;
+		}
+		MVDB_STAMP(7);
+	}
+
+	if (bail >= 0) {
+		// the query goes to traverse_kernel: it must find its visited bitmap clean
+		if (touched) {
+			uint4 *p = reinterpret_cast<uint4 *>(vis.p);
+			const size_t n16 = a.vis_stride / 16;
+			for (size_t i = lane; i < n16; i += 64) p[i] = make_uint4(0u, 0u, 0u, 0u);
+		}
+		if (lane == 0) {
+			a.flag[qi] = bail;
+			if (a.lean_stats) __hip_atomic_fetch_add(a.lean_stats + bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		return;
+	}
+	int out_count = res_size < a.k ? res_size : a.k;  // :1015-1017
+	if (out_count > a.results_cap) out_count = a.results_cap;
+	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
+#ifdef MVDB_TRAVERSE_PROFILE
+	if (lane == 0 && a.prof)
+		for (int i = 0; i < 16; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
+#endif
+	if (lane == 0) {
+		a.flag[qi] = kLeanDone;
+		a.adm_n[qi] = n_adm;
+		a.out_count[qi] = out_count;
+		if (a.ctr) {
+			mvdb_query_counters c;
+			c.n_dist = n_dist;
+			c.n_l0lists = n_l0;
+			c.n_upperlists = n_up;
+			c.n_found = out_count;
+			a.ctr[qi] = c;
+		}
+	}
+}
+
+// ---- the result heap, afterwards ---------------------------------------------------------------------------
+// One wave per query: res_push while the heap fills (:233-248), res_replace_root for every later admission
+// (:291-315, pipelined: HeapPipe), then res_to_sorted_full (:317-325) unless the caller only needs the set
+// (TraverseArgs::set_only).  Reads the log traverse_lean_kernel wrote; queries it flagged are skipped.
+__host__ __device__ inline size_t replay_lds_bytes(int ef, bool sorted)
+{
+	return (size_t)8 * (size_t)((ef + 3) & ~1) + (sorted ? (size_t)8 * (size_t)((ef + 1) & ~1) : 0);
+}
+
+__global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_lds)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const int lane = threadIdx.x;
+	const int qi = blockIdx.x;
+	if (qi >= a.nq) return;
+	if (rfl(a.flag[qi]) != kLeanDone) return;
+	const int ef = a.ef;
+	uint2 *res_h = reinterpret_cast<uint2 *>(lds_raw);
+	uint2 *out_s = res_h + ((ef + 3) & ~1);  // sorted output staging (only when sorted_lds)
+	const LdsHeap<false> res{res_h, (unsigned)(size_t)res_h};
+	HeapPipe<false> rpipe;
+	rpipe.base = (unsigned)(size_t)res_h;
+	const int n_adm = rfl(a.adm_n[qi]);
+	const uint2 *log = a.adm_log + (size_t)qi * (size_t)a.adm_log_cap;
+	int res_size = 0;
+	uint2 cur = lane < n_adm ? log[lane] : make_uint2(0u, 0u);
+	for (int c0 = 0; c0 < n_adm; c0 += 64) {
+		const uint2 nxt = c0 + 64 + lane < n_adm ? log[c0 + 64 + lane] : make_uint2(0u, 0u);
+		const int m = n_adm - c0 < 64 ? n_adm - c0 : 64;
+		for (int t = 0; t < m; t++) {
+			// keys as the reference holds them: the f32 value of the integer distance (math.ts:126)
+			const unsigned key = __float_as_uint((float)lean_readlane(cur.x, t));
+			const unsigned id = lean_readlane(cur.y, t);
+			if (res_size < ef) {
+				res.push(res_size++, (int)id, key, lane);  // :504-505
+			} else {
+				rpipe.tick();  // :506-507, see traverse_kernel
+				rpipe.issue(lane, res_size, key, id);
+				rpipe.tick();
+			}
+		}
+		cur = nxt;
+	}
+	rpipe.drain();
+	const int found = res_size;
+	const bool unsorted = a.set_only && found <= a.k && found <= a.results_cap && found <= MVDB_MAX_EF;
+	int out_count = found < a.k ? found : a.k;  // :1015-1017
+	if (out_count > a.results_cap) out_count = a.results_cap;
+	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
+	int32_t *oid = a.out_ids + (size_t)qi * (size_t)a.k;
+	float *od = a.out_dist + (size_t)qi * (size_t)a.k;
+	if (unsorted) {
+		for (int i = lane; i < out_count; i += 64) {
+			const uint2 e = res_h[1 + i];
+			oid[i] = (int)e.y;
+			od[i] = __uint_as_float(e.x);
+		}
+	} else if (sorted_lds) {
+		// res_to_sorted_full (:317-325): repeated max-heap pops, written back to front, pipelined
+		for (int i = 0; i < found; i++) {
+			const int last = found - i;  // slot of the entry this pop carries to the root
+			rpipe.tick();                // the previous pop leaves level 2
+			while (rpipe.on_chain_to(last)) rpipe.tick();
+			const uint2 root = res_h[1];
+			const uint2 e = res_h[last];
+			if (lane == 0) out_s[found - 1 - i] = root;
+			if (last > 1) {
+				rpipe.issue(lane, last - 1, e.x, e.y);
+				rpipe.tick();
+			}
+		}
+		rpipe.drain();
+		for (int i = lane; i < out_count; i += 64) {  // :1019-1024
+			const uint2 e = out_s[i];
+			oid[i] = (int)e.y;
+			od[i] = __uint_as_float(e.x);
+		}
+	}
+	for (int i = out_count + lane; i < a.k; i += 64) {  // deterministic tail of a ragged row
+		oid[i] = -1;
+		od[i] = 0.f;
+	}
+}
+
+}  // namespace mvdb

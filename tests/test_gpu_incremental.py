@@ -103,7 +103,7 @@ def test_patch_takes_the_full_upload_when_a_batch_outgrows_the_upper_slack(gpu):
     """The device keeps max(4096, lists/8) spare upper lists; a dirty batch whose SUMMED levels exceed what is left
     must take the full upload (which re-sizes the slack) -- not pass a per-node check and write past the array."""
     from minivectordb_amd import HipBridge
-    dim, m, efc, n, cap = 32, 8, 40, 3000, 16000
+    dim, m, efc, n, cap = 32, 8, 40, 3000, 40000      # cap / 4 dirty nodes is the patch limit: 700 inserts stay below
     b8 = O.quantize_rows_i8(gaussian_unit(n, dim, 3))
     b = HipBridge()
     b.init(dict(dim=dim, m=m, ef=efc, capacity=cap, seed=42))
@@ -121,4 +121,4 @@ def test_patch_takes_the_full_upload_when_a_batch_outgrows_the_upper_slack(gpu):
         _same_answers(b, _fresh(b.saveBytes(), dim, m, efc), q8, 100, 100)
         seen_second = seen_second or b.uploadCounters()["full_uploads"] >= 2
     c = b.uploadCounters()
-    assert seen_second and c["full_uploads"] == 2 and c["patches"] >= 5, c
+    assert seen_second and c["full_uploads"] == 2 and c["patches"] >= 6, c
