@@ -439,7 +439,8 @@ def run_hnsw(args, torch, dist, dev, rank, world):
     bytes_per_launch = bytes_timed / max(args.steps, 1)
     achieved = bytes_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
     m0 = 2 * pl.preset["m"]
-    kernel = "traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else "traverse_duo_kernel"
+    kernel = ("traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else
+              "traverse_duo_kernel" if args.traverse_waves in (2, 3) else "traverse_lean_kernel")
     traffic, traffic_source = traffic_record(pl, kernel)
     roofline = dict(bound="hbm", kernel=kernel, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
@@ -684,7 +685,8 @@ def main():
     ap.add_argument("--host-f32", action="store_true", help="float32 store in pinned host memory (preloadVectors=false)")
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
-    ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1, 2, 3], help="0 = the engine's default")
+    ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="0 = the engine's default (4 = the lean traversal + result-heap replay); 1-3 = result heap inside the traversal")
     ap.add_argument("--visited-mode", type=int, default=0, choices=[0, 1, 2],
                     help="visited-bitmap clean-up: 0 / 1 memset per launch (default), 2 the kernel's log-and-clear (measured slower)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",

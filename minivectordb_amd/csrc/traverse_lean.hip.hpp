@@ -40,7 +40,9 @@ namespace mvdb {
 constexpr int kLeanMaxM0 = 64;            // one 64-lane chunk per neighbour list
 constexpr unsigned kLeanKeyMax = 65535u;  // 16-bit keys
 constexpr unsigned kLeanInf = 0xffffffffu;
-constexpr int kLeanTake = 48;             // a refill moves at most this many entries into the window (16 lanes of headroom)
+constexpr int kLeanTake = 48;             // a sparse refill moves at most this many entries into the window
+constexpr int kLeanMaxIn = 12;            // admissions of one list that may join the window on the parallel path (48 + 12 <= 64 lanes)
+constexpr int kLeanLowSlack = 512;        // dead entries the flat key array may hold before it is compacted
 
 // flag[qi] after traverse_lean_kernel: what still has to happen to the query
 enum : int {
@@ -51,6 +53,12 @@ enum : int {
 	kLeanAborted = 4,   // test hook (mvdb_debug_inject_abort): reported as an aborted query
 };
 
+// LLVM's uniformity analysis marks EVERY phi of a join block divergent when a lane-dependent branch joins there,
+// also the ones that merge wave-uniform control flow ending in the same block -- and one such phi in the
+// expansion loop turns all of its scalar state into vector registers under EXEC masks.  An empty volatile asm
+// behind a lane-dependent `if` keeps its join block apart from the enclosing uniform one.
+#define MVDB_LANE_JOIN() asm volatile("")
+
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 __device__ __forceinline__ unsigned lds_r16(unsigned a) { return *reinterpret_cast<const lds_u16 *>((size_t)a); }
@@ -60,6 +68,14 @@ __device__ __forceinline__ void lds_w32(unsigned a, unsigned v) { *reinterpret_c
 
 __device__ __forceinline__ unsigned lean_readlane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ unsigned long long lean_lt_mask(int lane) { return (1ull << lane) - 1; }
+// a wave-uniform 64-bit mask the compiler could not prove uniform: pin it to scalar registers (loops over its bits
+// are scalar loops then, not waterfalls under EXEC)
+__device__ __forceinline__ unsigned long long lean_uni64(unsigned long long x)
+{
+	const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
 
 // minimum / maximum over the wave as a uniform value (DPP within rows of 16, then 4 readlanes)
 __device__ __forceinline__ unsigned lean_wave_min(unsigned x)
@@ -80,13 +96,21 @@ __device__ __forceinline__ unsigned lean_wave_max(unsigned x)
 	x = mx(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
 	return mx(mx(lean_readlane(x, 0), lean_readlane(x, 16)), mx(lean_readlane(x, 32), lean_readlane(x, 48)));
 }
+__device__ __forceinline__ unsigned lean_wave_sum(unsigned x)
+{
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false);
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false);
+	return lean_readlane(x, 0) + lean_readlane(x, 16) + lean_readlane(x, 32) + lean_readlane(x, 48);
+}
 // whole-wave shift by one lane (DPP wave_shr:1)
 __device__ __forceinline__ unsigned lean_shr1(unsigned x, unsigned fill)  // lane l <- lane l-1, lane 0 <- fill
 {
 	return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
 }
 
-// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | low keys u16[ef+64] | 4 x 64 dwords of buffers
+// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | flat result keys u16[ef+576] | 4 x 64 dwords of buffers
 struct LeanCarve {
 	unsigned ck, ci, lowk, buf;
 	size_t total;
@@ -100,7 +124,7 @@ __host__ __device__ inline LeanCarve lean_carve(int ef, int cand_cap)
 	c.ci = o;
 	o += ((unsigned)(cand_cap + 2) * 4u + 15u) & ~15u;
 	c.lowk = o;
-	o += ((unsigned)(ef + 64) * 2u + 15u) & ~15u;
+	o += ((unsigned)(ef + kLeanLowSlack + 64) * 2u + 15u) & ~15u;
 	c.buf = o;
 	o += 4u * 64u * 4u;
 	c.total = o;
@@ -162,6 +186,7 @@ struct LeanCand {
 				lds_w16(kb + 2u * (unsigned)(pos >> 1), ek);
 				lds_w32(ib + 4u * (unsigned)(pos >> 1), ei);
 			}
+			MVDB_LANE_JOIN();
 			const int dc = 31 - __builtin_clz(cur);
 			p = (p << dc) + (cur - (1 << dc));
 			if (steps < 5) break;
@@ -170,24 +195,32 @@ struct LeanCand {
 			lds_w16(kb + 2u * (unsigned)p, nkey);
 			lds_w32(ib + 4u * (unsigned)p, nid);
 		}
+		MVDB_LANE_JOIN();
 	}
 };
 
 // ---- the largest result keys, sorted in registers ---------------------------------------------------------
-// Lanes 0..V-1 hold DISTINCT key values in ascending order with their multiplicities.  Invariant: every key
-// of the result multiset that is >= T sits here; everything below T is in the flat LDS array.
+// Lanes 0..V-1 hold DISTINCT key values in ascending order with their multiplicities (`total` entries in all).
+// Invariant: every key of the result multiset that is >= T sits here; everything below T is in the flat LDS
+// array (whose entries >= T are dead: they moved here once and have been dropped since, or still sit here).
 struct KeyWin {
 	unsigned wk = 0, wc = 0;
-	int V = 0;
-	unsigned T = kLeanInf;
+	int V = 0, total = 0;
+	unsigned T = 0x10000u;
 	__device__ __forceinline__ unsigned worst() const { return lean_readlane(wk, V - 1); }
-	__device__ __forceinline__ void remove_max(int lane)
+	// drop the m largest entries (m <= total)
+	__device__ __forceinline__ void remove_largest(int m, int lane)
 	{
-		const unsigned c = lean_readlane(wc, V - 1);
-		if (c > 1u) {
-			if (lane == V - 1) wc -= 1u;
-		} else {
-			V -= 1;
+		total -= m;
+		while (m > 0) {
+			const int c = (int)lean_readlane(wc, V - 1);
+			if (c > m) {
+				wc -= lane == V - 1 ? (unsigned)m : 0u;
+				m = 0;
+			} else {
+				m -= c;
+				V -= 1;
+			}
 		}
 	}
 };
@@ -211,8 +244,9 @@ __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const Que
 		for (int pp = 0; pp < 4; pp++) {
 			if (p0 + pp * 8 < n) {
 				const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v[pp])));
-				if (slot[pp] < n) big = big || tot > kLeanKeyMax;
+				big = big || (slot[pp] < n && tot > kLeanKeyMax);
 				if (s == 0 && slot[pp] < n) dist_s[slot[pp]] = tot;
+				MVDB_LANE_JOIN();
 			}
 		}
 	}
@@ -249,6 +283,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 #endif
 
 	const int ef = a.ef, cand_cap = a.cand_cap, m0 = ix.m0;
+	const int lane_m0 = lane < m0 ? lane : m0 - 1;  // list loads are unconditional (lanes beyond the list re-read its last entry)
 	const LeanCarve cv = lean_carve(ef, cand_cap);
 	const unsigned lds0 = (unsigned)(size_t)lds_raw;
 	const LeanCand cand{lds0 + cv.ck, lds0 + cv.ci};
@@ -271,6 +306,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	unsigned cur_d;
 	{
 		if (lane == 0) all_ids[0] = cur;
+		MVDB_LANE_JOIN();
 		lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, 1, cur, lane, big);
 		cur_d = (unsigned)rfl((int)all_dist[0]);
 		n_dist++;
@@ -285,14 +321,15 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			if (lvl < l) continue;  // no list on this layer (corrupt graph): treated as empty
 			const int2 *lst = ix.upper + (size_t)(cum + l - 1) * (size_t)ix.m;
 			for (int base = 0; base < ix.m; base += 64) {
-				int2 en = make_int2(-1, -1);
-				if (base + lane < ix.m) en = lst[base + lane];
+				int2 en = lst[base + lane < ix.m ? base + lane : ix.m - 1];
+				if (base + lane >= ix.m) en = make_int2(-1, -1);
 				const int n = __builtin_popcountll(__ballot(en.x >= 0));  // canonical lists: valid entries are a prefix
 				if (n == 0) break;
 				if (en.x >= 0) {
 					all_ids[lane] = en.x;
 					buf_a[lane] = en.y;
 				}
+				MVDB_LANE_JOIN();
 				lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, n, cur, lane, big);
 				n_dist += n;
 				// sequential scan with strict `<` == first occurrence of the minimum, if below cur_d
@@ -316,88 +353,129 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	uint2 *log = a.adm_log + (size_t)qi * (size_t)a.adm_log_cap;
 	int cand_size = 0, res_size = 0, low_n = 0, n_adm = 0, s_hint = 0;
 	unsigned worst = kLeanInf;  // max of the result keys; consulted only once res_size >= ef
-	unsigned low_max = 0;       // max of the flat array (exact whenever a refill may need it)
-	unsigned fill_max = 0;      // per lane: keys appended while the result set was filling
+	const int low_cap = ef + kLeanLowSlack;
 	KeyWin win;
 
-	auto low_append1 = [&](unsigned d) {
-		if (lane == 0) lds_w16(lowk + 2u * (unsigned)low_n, d);
-		low_n++;
-		low_max = low_max > d ? low_max : d;
+	// keys < T stay, the dead ones go (the order of the flat array carries no meaning)
+	auto low_compact = [&]() __attribute__((always_inline)) {
+		int newn = 0;
+		for (int i0 = 0; i0 < low_n; i0 += 64) {
+			const int i = i0 + lane;
+			const bool valid = i < low_n;
+			const unsigned k = valid ? lds_r16(lowk + 2u * (unsigned)i) : 0u;
+			const bool keep = valid && k < win.T;
+			const unsigned long long km = __ballot(keep);
+			if (keep) lds_w16(lowk + 2u * (unsigned)(newn + __builtin_popcountll(km & lean_lt_mask(lane))), k);
+			MVDB_LANE_JOIN();
+			newn += __builtin_popcountll(km);
+		}
+		low_n = newn;
 	};
-	// window empty, flat array not: move the largest keys of the flat array into the window
-	auto refill = [&]() {
+	// the lanes of `mask` append their key to the flat array
+	auto low_append = [&](unsigned long long mask, unsigned my_d) __attribute__((always_inline)) {
+		const int n = __builtin_popcountll(mask);
+		if (low_n + n > low_cap) low_compact();  // <= ef alive entries remain
+		if ((mask >> lane) & 1ull) lds_w16(lowk + 2u * (unsigned)(low_n + __builtin_popcountll(mask & lean_lt_mask(lane))), my_d);
+		MVDB_LANE_JOIN();
+		low_n += n;
+	};
+	// 8 keys of the flat array per lane and step
+	auto low_vec = [&](int vi, int nvec) __attribute__((always_inline)) -> uint4 {
+		return vi < nvec ? lds_read16(reinterpret_cast<const void *>((size_t)(lowk + 16u * (unsigned)vi))) : make_uint4(0u, 0u, 0u, 0u);
+	};
+	auto low_key = [](const uint4 &kv, int e) __attribute__((always_inline)) -> unsigned {
+		const unsigned w = e < 2 ? kv.x : (e < 4 ? kv.y : (e < 6 ? kv.z : kv.w));
+		return (e & 1) ? w >> 16 : w & 0xffffu;
+	};
+	// window empty: move the largest alive keys of the flat array into it.  A histogram of the keys just below the
+	// floor T (64 bins of 2^s key values, bin 0 on top) finds the new floor: with bins of one key value the bins ARE
+	// the window (any multiplicity); with wider bins the largest prefix of bins holding <= kLeanTake entries is
+	// collected, sorted by counting and run-length encoded.  s adapts to the density of the keys.
+	auto refill = [&]() __attribute__((always_inline)) {
 #ifdef MVDB_TRAVERSE_PROFILE
 		const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #endif
-		const unsigned Kmax = low_max;
-		int s = s_hint, L = 0, acc = 0;
-		unsigned Tn = 0, hc = 0;
+		unsigned T = win.T, Tn = 0, hc = 0;
+		int s = s_hint, L = 0, acc = 0, limit = 64;
+		const int nvec = (low_n + 7) >> 3;
 		for (;;) {
-			// histogram of the keys just below Kmax, bins of 2^s key values, bin 0 on top
 			lds_w32(hist + 4u * (unsigned)lane, 0u);
-			for (int i0 = 0; i0 < low_n; i0 += 64) {
-				const int i = i0 + lane;
-				if (i < low_n) {
-					const unsigned b = (Kmax - lds_r16(lowk + 2u * (unsigned)i)) >> s;
-					if (b < 64u)
+			for (int v0 = 0; v0 < nvec; v0 += 64) {
+				const int vi = v0 + lane;
+				const uint4 kv = low_vec(vi, nvec);
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const unsigned k = low_key(kv, e);
+					const unsigned b = (T - 1u - k) >> s;  // k >= T wraps far beyond 64 bins
+					if (vi < nvec && 8 * vi + e < low_n && k < T && b < 64u)
 						__hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)(hist + 4u * b)), 1u, __ATOMIC_RELAXED,
 						                       __HIP_MEMORY_SCOPE_WORKGROUP);
+					MVDB_LANE_JOIN();
 				}
 			}
-			hc = lds_r32(hist + 4u * (unsigned)lane);
-			if (s == 0) {  // a bin is a key value: the bins ARE the window, any multiplicity
-				Tn = Kmax >= 63u ? Kmax - 63u : 0u;
+			const unsigned long long nz0 = __ballot(lds_r32(hist + 4u * (unsigned)lane) != 0u);
+			if (nz0 == 0ull) {  // nothing alive within 64 bins below T: the floor drops past the gap, bins get coarser
+				const unsigned span = 64u << s;
+				if (T <= span) {  // no alive key at all: the multiset invariant is broken (never observed)
+					bail = kLeanMismatch;
+					return;
+				}
+				T -= span;
+				s = s + 3 < 10 ? s + 3 : 10;
+				continue;
+			}
+			const int f = __builtin_ctzll(nz0);
+			T -= (unsigned)f << s;  // no alive key in [T - (f << s), T): the floor drops to the first occupied bin
+			limit = 64 - f;
+			hc = lane < limit ? lds_r32(hist + 4u * (unsigned)(lane + f)) : 0u;
+			if (s == 0) {
+				Tn = T >= (unsigned)limit ? T - (unsigned)limit : 0u;
 				break;
 			}
 			L = 0;
 			acc = 0;
-			for (; L < 64; L++) {  // the largest prefix of bins holding <= kLeanTake entries
+			for (; L < limit; L++) {  // the largest prefix of bins holding <= kLeanTake entries
 				const int c = (int)lean_readlane(hc, L);
 				if (acc + c > kLeanTake) break;
 				acc += c;
 			}
 			if (L > 0) {
 				const unsigned span = (unsigned)L << s;
-				Tn = Kmax + 1u > span ? Kmax + 1u - span : 0u;
+				Tn = T > span ? T - span : 0u;
 				break;
 			}
 			s = s > 3 ? s - 3 : 0;  // the top bin alone is too crowded: finer bins
 		}
 		const bool dense = s == 0;
-		// keys >= Tn leave the flat array (compacted in place; its order carries no meaning)
-		int newn = 0, cpos = 0;
-		unsigned rmax = 0;
-		for (int i0 = 0; i0 < low_n; i0 += 64) {
-			const int i = i0 + lane;
-			const bool valid = i < low_n;
-			const unsigned k = valid ? lds_r16(lowk + 2u * (unsigned)i) : 0u;
-			const bool take = valid && k >= Tn;
-			const bool keep = valid && !take;
-			if (!dense) {
-				const unsigned long long tm = __ballot(take);
-				if (take) lds_w32(stage + 4u * (unsigned)(cpos + __builtin_popcountll(tm & lean_lt_mask(lane))), k);
-				cpos += __builtin_popcountll(tm);
-			}
-			const unsigned long long km = __ballot(keep);
-			if (keep) lds_w16(lowk + 2u * (unsigned)(newn + __builtin_popcountll(km & lean_lt_mask(lane))), k);
-			newn += __builtin_popcountll(km);
-			rmax = keep && k > rmax ? k : rmax;
-		}
-		const int taken = low_n - newn;
-		low_n = newn;
-		low_max = lean_wave_max(rmax);
 		if (dense) {
 			const unsigned long long nz = __ballot(hc != 0u);
-			const unsigned long long above = lane == 63 ? 0ull : (nz >> (lane + 1));  // bins below this key value
-			if (hc != 0u) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(above), ((Kmax - (unsigned)lane) & 0xffffu) | (hc << 16));
+			const unsigned long long above = lane == 63 ? 0ull : (nz >> (lane + 1));  // occupied bins of smaller key values
+			if (hc != 0u) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(above), ((T - 1u - (unsigned)lane) & 0xffffu) | (hc << 16));
+			MVDB_LANE_JOIN();
 			const unsigned v = lds_r32(stage + 4u * (unsigned)lane);
 			win.wk = v & 0xffffu;
 			win.wc = v >> 16;
 			win.V = __builtin_popcountll(nz);
-			s_hint = taken < 12 ? 2 : 0;
+			win.total = (int)lean_wave_sum(hc);
+			s_hint = win.total >= 24 ? 0 : (win.total >= 12 ? 1 : (win.total >= 6 ? 2 : 3));
 		} else {
-			const int cnt = cpos;  // <= kLeanTake
+			// collect the keys in [Tn, T): acc <= kLeanTake of them, in any order
+			lds_w32(hist, 0u);
+			for (int v0 = 0; v0 < nvec; v0 += 64) {
+				const int vi = v0 + lane;
+				const uint4 kv = low_vec(vi, nvec);
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const unsigned k = low_key(kv, e);
+					if (vi < nvec && 8 * vi + e < low_n && k < T && k >= Tn) {
+						const unsigned pos = __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)hist), 1u, __ATOMIC_RELAXED,
+						                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+						lds_w32(stage + 4u * pos, k);
+					}
+					MVDB_LANE_JOIN();
+				}
+			}
+			const int cnt = acc;
 			const unsigned key = lane < cnt ? lds_r32(stage + 4u * (unsigned)lane) : kLeanInf;
 			unsigned lt = 0, eqb = 0;  // rank by counting
 			for (int j = 0; j < cnt; j++) {
@@ -406,6 +484,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				eqb += (kj == key && j < lane) ? 1u : 0u;
 			}
 			if (lane < cnt) lds_w32(hist + 4u * (lt + eqb), key);
+			MVDB_LANE_JOIN();
 			const unsigned sk = lane < cnt ? lds_r32(hist + 4u * (unsigned)lane) : kLeanInf;
 			const unsigned prev = lean_shr1(sk, kLeanInf);
 			const bool head = lane < cnt && (lane == 0 || sk != prev);
@@ -413,11 +492,14 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
 			const int next = above ? lane + 1 + __builtin_ctzll(above) : cnt;
 			if (head) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(hm & lean_lt_mask(lane)), sk | ((unsigned)(next - lane) << 16));
+			MVDB_LANE_JOIN();
 			const unsigned v = lds_r32(stage + 4u * (unsigned)lane);
 			win.wk = v & 0xffffu;
 			win.wc = v >> 16;
 			win.V = __builtin_popcountll(hm);
-			s_hint = (L == 64 && acc < 24) ? (s < 10 ? s + 1 : 10) : (L < 6 ? s - 1 : s);
+			win.total = cnt;
+			const int span = L << s;
+			s_hint = (L == limit && acc < 24) ? (s < 10 ? s + 1 : 10) : (span <= 80 ? 0 : (L < 16 ? s - 1 : s));
 		}
 		win.T = Tn;
 		MVDB_LEAN_COUNT(10, 1);
@@ -427,115 +509,136 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 #endif
 	};
 	// d >= win.T joins the window
-	auto win_insert = [&](unsigned d) {
+	auto win_insert = [&](unsigned d) __attribute__((always_inline)) {
+		win.total += 1;
 		const bool valid = lane < win.V;
 		const unsigned long long eq = __ballot(valid && win.wk == d);
 		if (eq) {
-			if (lane == __builtin_ctzll(eq)) win.wc += 1u;
+			win.wc += lane == __builtin_ctzll(eq) ? 1u : 0u;
 			return;
 		}
-		// A free lane always exists: a sparse refill brings at most kLeanTake entries and the number of entries at or
-		// above T never grows (every admission removes one of them), a dense window spans 64 key values.
+		// A free lane always exists: a sparse refill brings at most kLeanTake entries, the number of entries at or
+		// above T never grows from list to list (every admission removes one of them) and a list adds at most
+		// kLeanMaxIn before its removals; a dense window spans at most 64 key values.
 		if (win.V == 64) {
 			bail = kLeanMismatch;
 			return;
 		}
-		const int r = __builtin_popcountll(__ballot(lane < win.V && win.wk < d));
+		const int r = __builtin_popcountll(__ballot(valid && win.wk < d));
 		const unsigned sk = lean_shr1(win.wk, 0u), sc = lean_shr1(win.wc, 0u);
-		if (lane > r) {
-			win.wk = sk;
-			win.wc = sc;
-		}
-		if (lane == r) {
-			win.wk = d;
-			win.wc = 1u;
-		}
+		win.wk = lane > r ? sk : (lane == r ? d : win.wk);
+		win.wc = lane > r ? sc : (lane == r ? 1u : win.wc);
 		win.V += 1;
 	};
-	// admission of a list in list order (:499-508) on the key multiset; returns the admitted lanes.  Logs them.
-	auto admit_list = [&](int n, unsigned my_d, int my_id) -> unsigned long long {
-		unsigned long long adm = 0, rem = n >= 64 ? ~0ull : ((1ull << n) - 1);
-		if (res_size < ef) {  // :504-505 while the result set fills up everything is admitted
-			const int f = n < ef - res_size ? n : ef - res_size;
-			if (lane < f) {
-				lds_w16(lowk + 2u * (unsigned)(low_n + lane), my_d);
-				fill_max = fill_max > my_d ? fill_max : my_d;
-			}
-			low_n += f;
-			res_size += f;
-			adm = f >= 64 ? ~0ull : ((1ull << f) - 1);
-			rem &= ~adm;
-			if (res_size >= ef) {
-				low_max = lean_wave_max(fill_max);
-				refill();
-				worst = win.worst();
-			}
-		}
-		while (rem) {  // full: `worst` only falls, so a neighbour rejected once stays rejected
-			const unsigned long long m = __ballot(my_d < worst) & rem;
-			if (!m) break;
-			const int t = __builtin_ctzll(m);
-			rem &= ~((2ull << t) - 1);
-			adm |= 1ull << t;
-			const unsigned d = lean_readlane(my_d, t);
-			win.remove_max(lane);  // :506-507 replace_root drops the largest key ...
-			if (d >= win.T) win_insert(d);  // ... and d joins the multiset
-			else low_append1(d);
-			if (bail >= 0) return adm;
-			if (win.V == 0) refill();
-			worst = win.worst();
-		}
-		const int na = __builtin_popcountll(adm);
-		MVDB_LEAN_COUNT(9, na);
-		if (n_adm + na > a.adm_log_cap) {
-			bail = kLeanLogFull;
-			return adm;
-		}
-		if ((adm >> lane) & 1ull) log[n_adm + __builtin_popcountll(adm & lean_lt_mask(lane))] = make_uint2(my_d, (unsigned)my_id);
-		n_adm += na;
-		return adm;
-	};
+	// Admission of a list in list order (:499-508) on the key multiset; returns the admitted lanes and logs them.
+	// Sequentially: neighbour i is admitted iff d_i < worst_i, the largest key left after the admissions before it.
+	// The result multiset after i-1 neighbours is the ef smallest keys of (M0 + d_0..d_{i-1}), so
+	//     admitted_i  <=>  #{j < i : d_j <= d_i}  <  #{x in M0 : x > d_i}      (M0 = the multiset the list meets).
+	// Only neighbours below the current worst can be admitted (B); for one below the floor T the right-hand side is
+	// at least the window's size, which the left-hand side cannot reach while |B| <= that size: admitted.  Only the few
+	// that land inside the window need the two counts.  The multiset afterwards = M0 + admitted - the |admitted| largest.
+	//   (the code sits inline in the expansion loop below: one call site for the refill, nothing left to a closure)
 
 	// the entry point (:450-454): dist0 re-evaluates the row the descent ended on (counted, not re-read)
 	n_dist++;
 	unsigned long long pend = 0;  // pushes waiting for the candidate heap: lanes of (p_d, p_id)
-	unsigned p_d = cur_d;
-	int p_id = cur;
+	unsigned p_d = 0;
+	int p_id = -1;
 	int c_id = cur;  // the candidate to expand next, known before the heap has seen it
 	unsigned c_d = cur_d;
-	if (bail < 0) {
-		if (lane == 0) vis.mark(cur);  // :452
-		touched = true;
-		pend = admit_list(1, lane == 0 ? cur_d : kLeanInf, cur) & 1ull;  // :453-454
-	}
 	int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
+	int pre2_id = -1, pre2_nb = -1;  // list fetched ahead for the nearest new neighbour of the last list
 	int seen_listed = 0, seen_new = 0;  // decaying counts: rows with the visited test while at least half were new
 	int o_id = -1;
 	unsigned o_key = 0;
+	bool first = true;  // the entry point goes through the loop once as a list of one new neighbour, without a memory phase
+	if (bail < 0) {
+		if (lane == 0) vis.mark(cur);  // :452
+		MVDB_LANE_JOIN();
+		touched = true;
+	}
 
-	while (bail < 0) {
-		if (res_size >= ef && c_d > worst) break;  // :466 (strict >)
-		int nb = -1;
-		if (pref_id == c_id) nb = pref_nb;
-		else {
-			if (lane < m0) nb = ix.adj0[(size_t)c_id * (size_t)m0 + lane];
-			MVDB_LEAN_COUNT(8, 1);
-		}
-		const int cnt = __builtin_popcountll(__ballot(nb >= 0));  // canonical lists: valid prefix
-		// candidate-heap work of this expansion, placed under the loads: the pushes the previous list admitted
-		// (:500-502), then cand_pop of this candidate (:460) and the fetch of the list of the root it leaves
-		auto heap_work = [&]() {
+	while (rfl(bail) < 0) {
+		// every piece of per-query state below is wave-uniform; pinning it to scalar registers at the top of the
+		// iteration keeps the loop's control flow on the scalar unit (not EXEC-masked regions over vector copies)
+#define MVDB_LEAN_PIN()                             \
+	do {                                                \
+		bail = rfl(bail);                               \
+		cand_size = rfl(cand_size);                     \
+		res_size = rfl(res_size);                       \
+		low_n = rfl(low_n);                             \
+		n_adm = rfl(n_adm);                             \
+		s_hint = rfl(s_hint);                           \
+		worst = (unsigned)rfl((int)worst);              \
+		win.V = rfl(win.V);                             \
+		win.total = rfl(win.total);                     \
+		win.T = (unsigned)rfl((int)win.T);              \
+		c_id = rfl(c_id);                               \
+		c_d = (unsigned)rfl((int)c_d);                  \
+		o_id = rfl(o_id);                               \
+		o_key = (unsigned)rfl((int)o_key);              \
+		pref_id = rfl(pref_id);                         \
+		pre2_id = rfl(pre2_id);                         \
+		seen_listed = rfl(seen_listed);                 \
+		seen_new = rfl(seen_new);                       \
+		n_l0 = rfl(n_l0);                               \
+		n_dist = rfl(n_dist);                           \
+	} while (0)
+		MVDB_LEAN_PIN();
+		int n = 0;
+		unsigned my_d = kLeanInf;
+		int my_id = -1;
+		if (first) {
+			n = 1;  // :453-454
+			my_d = lane == 0 ? cur_d : kLeanInf;
+			my_id = lane == 0 ? cur : -1;
+		} else {
+			if (res_size >= ef && c_d > worst) break;  // :466 (strict >)
+			// (every lane loads, lanes beyond the list re-read its last entry; the mask is applied HERE, where the words
+			// are needed -- masking at the load would wait for it on the spot)
+			int nb = -1;
+			if (pref_id == c_id) nb = pref_nb;
+			else if (pre2_id == c_id) nb = pre2_nb;
+			else {
+				nb = ix.adj0[(size_t)c_id * (size_t)m0 + lane_m0];
+				MVDB_LEAN_COUNT(8, 1);
+			}
+			nb = lane < m0 ? nb : -1;
+			const int cnt = __builtin_popcountll(__ballot(nb >= 0));  // canonical lists: valid prefix
+			// ---- issue the memory phase: visited test-and-set (:494-495) and, while at least half of the recently
+			// listed neighbours were new, the rows of EVERY listed neighbour with it (one round trip instead of two)
+			const bool spec = cnt > 0 && 2 * seen_new >= seen_listed;
+			const int g = lane >> 3, sl = lane & 7;
+			unsigned old = 0;
+			int4 v0[4][J];  // 32 rows per pass, all in flight at once
+			int slot0[4];
+			if (cnt > 0 && nb >= 0) old = vis.probe(nb);
+			MVDB_LANE_JOIN();
+			if (spec) {
+				if (nb >= 0) all_ids[lane] = nb;
+				MVDB_LANE_JOIN();
+#pragma unroll
+				for (int pp = 0; pp < 4; pp++) {
+					slot0[pp] = pp * 8 + g;
+					const int rid = slot0[pp] < cnt ? all_ids[slot0[pp]] : c_id;
+					if (pp * 8 < cnt) load_row<J, FULL>(v0[pp], ix, rid, sl);
+				}
+			}
 			MVDB_STAMP(1);
-			for (unsigned long long m = pend; m; m &= m - 1) {
+			// ---- candidate-heap work of this expansion, under the loads: the pushes the previous list admitted
+			// (:500-502), then cand_pop of this candidate (:460) and the fetch of the list of the root it leaves
+			for (unsigned long long m = lean_uni64(pend); m; m &= m - 1) {
 				const int t = __builtin_ctzll(m);
 				cand.push(cand_size++, (unsigned)__builtin_amdgcn_readlane(p_id, t), lean_readlane(p_d, t), lane);
 			}
 			pend = 0;
-			const unsigned rk = (unsigned)rfl((int)cand.key_at(1));
-			const int ri = rfl((int)cand.id_at(1));
-			if (cand_size <= 0 || ri != c_id || rk != c_d) {
-				bail = kLeanMismatch;
-				return;
+			{
+				const unsigned rk = (unsigned)rfl((int)cand.key_at(1));
+				const int ri = rfl((int)cand.id_at(1));
+				if (cand_size <= 0 || ri != c_id || rk != c_d) {
+					bail = kLeanMismatch;
+					break;
+				}
 			}
 			cand_size--;
 			if (cand_size > 0) {
@@ -546,69 +649,42 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				o_id = rfl((int)cand.id_at(1));
 				if (pref_id != o_id) {  // needed next unless a new neighbour undercuts it
 					pref_id = o_id;
-					pref_nb = -1;
-					if (lane < m0) pref_nb = ix.adj0[(size_t)o_id * (size_t)m0 + lane];
+					pref_nb = ix.adj0[(size_t)o_id * (size_t)m0 + lane_m0];
 				}
 			}
 			MVDB_STAMP(2);
-		};
-
-		int n = 0;
-		unsigned my_d = kLeanInf;
-		int my_id = -1;
-		if (cnt == 0) {
-			heap_work();
-		} else {
-			const unsigned old = nb >= 0 ? vis.probe(nb) : 0u;  // :494-495 visited test-and-set
-			if (2 * seen_new < seen_listed) {
-				// rows of the NEW neighbours only, after the visited words are back
-				heap_work();
-				const bool isnew = nb >= 0 && !vis.seen(old, nb);
-				const unsigned long long nm = __ballot(isnew);
-				n = __builtin_popcountll(nm);
-				seen_listed += cnt - (seen_listed >> 2);
-				seen_new += n - (seen_new >> 2);
-				MVDB_STAMP(4);
-				if (n > 0) {
-					if (isnew) buf_a[__builtin_popcountll(nm & lean_lt_mask(lane))] = nb;
-					lean_dist_rows<J, FULL>(ix, Q, buf_a, buf_b, n, c_id, lane, big);  // :497
-					my_d = lane < n ? buf_b[lane] : kLeanInf;
-					my_id = lane < n ? buf_a[lane] : -1;
-				}
-				MVDB_STAMP(3);
-			} else {
-				// rows of every listed neighbour together with the visited test (one memory round trip instead of
-				// two; most listed neighbours are new while the search is still spreading)
-				if (nb >= 0) all_ids[lane] = nb;
-				const int g = lane >> 3, sl = lane & 7;
-				// 32 rows per pass, all in flight at once; no loop around the passes (a loop makes the compiler
-				// drain vmcnt before every reuse of the row registers)
-				auto pass = [&](const int p0, const bool first) {
-					int4 v[4][J];
-					int slot[4];
+			// ---- distances of the new neighbours, in list order
+			if (spec) {
 #pragma unroll
-					for (int pp = 0; pp < 4; pp++) {
-						slot[pp] = p0 + pp * 8 + g;
-						const int rid = slot[pp] < cnt ? all_ids[slot[pp]] : c_id;
-						if (p0 + pp * 8 < cnt) load_row<J, FULL>(v[pp], ix, rid, sl);
+				for (int pp = 0; pp < 4; pp++) {
+					if (pp * 8 < cnt) {
+						const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v0[pp])));
+						if (sl == 0 && slot0[pp] < cnt) all_dist[slot0[pp]] = tot;
+						MVDB_LANE_JOIN();
 					}
-					if (first) heap_work();
+				}
+				if (cnt > 32) {  // lists of up to 64 neighbours: a second pass
+					int4 v1[4][J];
+					int slot1[4];
 #pragma unroll
 					for (int pp = 0; pp < 4; pp++) {
-						if (p0 + pp * 8 < cnt) {
-							const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v[pp])));
-							if (sl == 0 && slot[pp] < cnt) all_dist[slot[pp]] = tot;
+						slot1[pp] = 32 + pp * 8 + g;
+						const int rid = slot1[pp] < cnt ? all_ids[slot1[pp]] : c_id;
+						if (32 + pp * 8 < cnt) load_row<J, FULL>(v1[pp], ix, rid, sl);
+					}
+#pragma unroll
+					for (int pp = 0; pp < 4; pp++) {
+						if (32 + pp * 8 < cnt) {
+							const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v1[pp])));
+							if (sl == 0 && slot1[pp] < cnt) all_dist[slot1[pp]] = tot;
+							MVDB_LANE_JOIN();
 						}
 					}
-				};
-				pass(0, true);
-				if (cnt > 32) pass(32, false);
+				}
 				MVDB_STAMP(3);
 				const bool isnew = nb >= 0 && !vis.seen(old, nb);
 				const unsigned long long nm = __ballot(isnew);
 				n = __builtin_popcountll(nm);
-				seen_listed += cnt - (seen_listed >> 2);
-				seen_new += n - (seen_new >> 2);
 				if (isnew) {
 					const int pos = __builtin_popcountll(nm & lean_lt_mask(lane));
 					const unsigned dd = all_dist[lane];  // :497
@@ -616,31 +692,156 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 					buf_a[pos] = nb;
 					buf_b[pos] = dd;
 				}
+				MVDB_LANE_JOIN();
 				my_d = lane < n ? buf_b[lane] : kLeanInf;
 				my_id = lane < n ? buf_a[lane] : -1;
 				MVDB_STAMP(4);
+			} else if (cnt > 0) {
+				// rows of the NEW neighbours only, after the visited words are back
+				const bool isnew = nb >= 0 && !vis.seen(old, nb);
+				const unsigned long long nm = __ballot(isnew);
+				n = __builtin_popcountll(nm);
+				MVDB_STAMP(4);
+				if (n > 0) {
+					if (isnew) buf_a[__builtin_popcountll(nm & lean_lt_mask(lane))] = nb;
+					MVDB_LANE_JOIN();
+					lean_dist_rows<J, FULL>(ix, Q, buf_a, buf_b, n, c_id, lane, big);  // :497
+					my_d = lane < n ? buf_b[lane] : kLeanInf;
+					my_id = lane < n ? buf_a[lane] : -1;
+				}
+				MVDB_STAMP(3);
+			}
+			if (cnt > 0) {
+				seen_listed += cnt - (seen_listed >> 2);
+				seen_new += n - (seen_new >> 2);
+			}
+			if (__ballot(big)) {
+				bail = kLeanBigKey;
+				break;
+			}
+			n_l0++;
+			n_dist += n;
+			// The nearest new neighbour is popped next whenever it is admitted and undercuts the root the pop left (see
+			// below): its list is asked for NOW, so that it travels while the list is being admitted.  A hint only.
+			if (n > 0) {
+				const unsigned dm = lean_wave_min(my_d);
+				if ((res_size < ef || dm < worst) && (cand_size == 0 || dm < o_key)) {
+					const int g_id = __builtin_amdgcn_readlane(my_id, __builtin_ctzll(__ballot(my_d == dm)));
+					if (g_id != pref_id && g_id != pre2_id) {
+						pre2_id = g_id;
+						pre2_nb = ix.adj0[(size_t)g_id * (size_t)m0 + lane_m0];
+					}
+				}
 			}
 		}
-		if (bail >= 0) break;
-		if (__ballot(big)) {
-			bail = kLeanBigKey;
-			break;
+		first = false;
+		n = rfl(n);
+
+		// ---- admission (see above)
+		unsigned long long adm = 0;
+		if (n > 0) {
+			unsigned long long rem = n >= 64 ? ~0ull : ((1ull << n) - 1);
+			bool need_refill = false;
+			if (res_size < ef) {  // :504-505 while the result set fills up everything is admitted
+				const int f = n < ef - res_size ? n : ef - res_size;
+				if (lane < f) lds_w16(lowk + 2u * (unsigned)(low_n + lane), my_d);
+				MVDB_LANE_JOIN();
+				low_n += f;
+				res_size += f;
+				adm = f >= 64 ? ~0ull : ((1ull << f) - 1);
+				rem &= ~adm;
+				if (res_size >= ef) {  // full: the floor starts just above the largest key
+					unsigned mx = 0;
+					const int nvec = (low_n + 7) >> 3;
+					for (int v0i = 0; v0i < nvec; v0i += 64) {
+						const int vi = v0i + lane;
+						const uint4 kv = low_vec(vi, nvec);
+#pragma unroll
+						for (int e = 0; e < 8; e++) {
+							const unsigned k = low_key(kv, e);
+							mx = (vi < nvec && 8 * vi + e < low_n && k > mx) ? k : mx;
+						}
+					}
+					win.T = lean_wave_max(mx) + 1u;
+					need_refill = true;
+				}
+			}
+			for (;;) {
+				if (need_refill) {
+					refill();
+					if (bail >= 0) break;
+					worst = win.worst();
+					need_refill = false;
+				}
+				if (!rem || res_size < ef) break;
+				MVDB_STAMP(13);
+				const unsigned long long B = lean_uni64(__ballot(my_d < worst) & rem);  // `worst` only falls: the others stay rejected
+				const int nB = __builtin_popcountll(B);
+				if (nB == 0) break;
+				const unsigned long long inwin = lean_uni64(__ballot(my_d >= win.T) & B);
+				if (nB <= win.total && __builtin_popcountll(inwin) <= kLeanMaxIn) {
+					unsigned long long ok = B & ~inwin;
+					for (unsigned long long mm = inwin; mm; mm &= mm - 1) {
+						const int i = __builtin_ctzll(mm);
+						const unsigned di = lean_readlane(my_d, i);
+						const int before = __builtin_popcountll(__ballot(my_d <= di) & B & lean_lt_mask(i));
+						const int le = (int)lean_wave_sum((lane < win.V && win.wk <= di) ? win.wc : 0u);
+						if (before < win.total - le) ok |= 1ull << i;
+					}
+					ok = lean_uni64(ok);
+					MVDB_STAMP(14);
+					for (unsigned long long mm = ok & inwin; mm; mm &= mm - 1) win_insert(lean_readlane(my_d, __builtin_ctzll(mm)));
+					if (bail >= 0) break;
+					if (ok & ~inwin) low_append(ok & ~inwin, my_d);
+					MVDB_STAMP(15);
+					win.remove_largest(__builtin_popcountll(ok), lane);  // :506-507 every replace_root drops the largest key
+					adm |= ok;
+					rem = 0;
+					if (win.V == 0) {
+						need_refill = true;
+						continue;
+					}
+					worst = win.worst();
+					break;
+				}
+				// one at a time (a nearly empty window, or many keys landing inside it): the first neighbour of B
+				const int t = __builtin_ctzll(B);
+				rem &= ~((2ull << t) - 1);
+				adm |= 1ull << t;
+				const unsigned d = lean_readlane(my_d, t);
+				win.remove_largest(1, lane);
+				if (d >= win.T) win_insert(d);
+				else low_append(1ull << t, my_d);
+				if (bail >= 0) break;
+				if (win.V == 0) {
+					need_refill = true;
+					continue;
+				}
+				worst = win.worst();
+			}
+			if (bail >= 0) break;
+			adm = lean_uni64(adm);
+			const int na = __builtin_popcountll(adm);
+			MVDB_LEAN_COUNT(9, na);
+			if (n_adm + na > a.adm_log_cap) {
+				bail = kLeanLogFull;
+				break;
+			}
+			if ((adm >> lane) & 1ull) log[n_adm + __builtin_popcountll(adm & lean_lt_mask(lane))] = make_uint2(my_d, (unsigned)my_id);
+			MVDB_LANE_JOIN();
+			n_adm += na;
 		}
-		n_l0++;
-		n_dist += n;
-		const unsigned long long adm = n > 0 ? admit_list(n, my_d, my_id) : 0ull;
-		if (bail >= 0) break;
 		MVDB_STAMP(5);
 		// ---- who is popped next.  Of the admitted neighbours the first `room` are pushed (:500); after those pushes
 		// the root is the first-pushed minimum if it is strictly below the root the pop left (:163), else that root.
 		const int room = cand_cap - cand_size;
 		unsigned long long pushed = room > 0 ? adm : 0ull;
 		while (__builtin_popcountll(pushed) > room) pushed &= ~(1ull << (63 - __builtin_clzll(pushed)));
-		pend = pushed;
+		pend = lean_uni64(pushed);
 		p_d = my_d;
 		p_id = my_id;
-		if (pushed) {
-			const unsigned pd = ((pushed >> lane) & 1ull) ? my_d : kLeanInf;
+		if (pend) {
+			const unsigned pd = ((pend >> lane) & 1ull) ? my_d : kLeanInf;
 			const unsigned dmin = lean_wave_min(pd);
 			if (cand_size == 0 || dmin < o_key) {
 				const int idx = __builtin_ctzll(__ballot(pd == dmin));  // first occurrence

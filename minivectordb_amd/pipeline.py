@@ -190,7 +190,14 @@ class ResidentSearcher:
     def merge_blocks(self, full: torch.Tensor, nq: int):
         """Merge gathered per-shard blocks [parts, block_bytes] by (l2, id) on the device -> a TopkBlock."""
         parts = int(full.shape[0])
-        out = TopkBlock(nq, self.topk, device=self.device)
+        # merged blocks come from a small ring allocated once per shape (no allocation per step; four merged
+        # results may be alive at a time, as many as batches can be in flight)
+        ring = getattr(self, "_merged_ring", None)
+        if ring is None or ring[0].nq != int(nq):
+            ring = self._merged_ring = [TopkBlock(nq, self.topk, device=self.device) for _ in range(4)]
+            self._merged_i = 0
+        out = ring[self._merged_i % len(ring)]
+        self._merged_i += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         ok = self.L.mvdb_merge_topk_packed_dev(self.h, C.c_void_p(full.data_ptr()), parts, int(nq), self.topk,
                                                C.c_void_p(out.ids.data_ptr()), C.c_void_p(out.l2.data_ptr()),
