@@ -10,16 +10,22 @@ batches; `--n 10000000` is the north-star size (10M x 384 balanced on one GPU).
   N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 What one run reports (ONE JSON line, rank 0):
-  value                    K timed steps, inputs resident, `--in-flight` batches overlapping on as many streams,
-                           `--batches` DISTINCT query batches rotated (no batch is answered twice in a row)
-  median_ms_per_step       median interval between consecutive batch completions (HIP events)
-  pcie_inclusive           the same steps with the H2D of the queries and the D2H of the results inside (N=1)
-  sustained                the same steps repeated for >= `--sustain-s` seconds
+  value                    K timed steps; every step copies its query batch from pinned host memory (H2D) and its
+                           result block back (D2H) -- SURVEY.md 8(d) counts both; `--in-flight` batches overlap on as
+                           many streams, `--batches` DISTINCT query batches rotate (no batch is answered twice in a row)
+  resident                 the same steps on batches already in HBM, results left in HBM (no copies)
+  sustained                >= 12 windows of >= 20 steps back to back (>= `--sustain-s` seconds); `median_ms_per_step`
+                           is the median window duration / steps per window (stream events, no drain between windows)
+  host_slots               the same work through mvdb_query_many_submit/_wait on pageable host buffers
   roofline                 traversal kernel: algorithmic bytes per launch (from the kernel's own
-                           counters) / mean launch duration (HIP events on the launching stream, timed region only)
+                           counters) / mean launch duration (HIP events on the launching stream, timed region only);
+                           `frac_structured` = the same figure on the clustered set
   cpu_baseline             the C oracle (a restatement of the WASM path) on a bounded sample, 1 thread and all cores;
                            the same leg asserts that the GPU results equal the oracle's on that sample
   second_dataset           the same pipeline on a clustered set (neighbourhood structure, recall >= 0.9)
+  scan_1m_512              BASELINE configs[2]: exact int8 scan on the matrix cores, 1M x 512, 4096 queries
+  north_star_10m           the north-star size, 10M x 384 balanced on this GPU: value, recall, roofline, cpu_baseline
+(`--legs none` drops the last three; they run by default only for the default 1M x 384 single-GPU line.)
 N>1: headline = SHARDED (each rank an id-range shard of `--n` vectors with its own sub-index, every
 rank sees every query, ONE packed all-gather of the per-shard top-k per batch + (l2, id) merge); `replicas` = the
 ranks answering their own batches with no exchange, as a second field.
@@ -80,11 +86,22 @@ def run_with_heartbeat(fn, what):
 
 
 def make_rows(n, dim, seed, clustered):
-    """Synthetic rows before normalisation: i.i.d. N(0,1) or a Gaussian mixture."""
-    rng = np.random.default_rng(seed)
+    """Synthetic rows before normalisation: i.i.d. N(0,1) or a Gaussian mixture.
+    Above 2 M rows the chunks are drawn by a small thread pool, one generator per chunk (numpy drops the GIL)."""
     out = np.empty((n, dim), np.float32)
-    centers = rng.standard_normal((CLUSTERS, dim), dtype=np.float32) if clustered else None
     chunk = 131072
+    if n > 2_000_000 and not clustered:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def fill(ci):
+            s0 = ci * chunk
+            c = min(chunk, n - s0)
+            np.random.default_rng([seed, ci]).standard_normal((c, dim), dtype=np.float32, out=out[s0:s0 + c])
+        with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+            list(ex.map(fill, range(-(-n // chunk))))
+        return out
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((CLUSTERS, dim), dtype=np.float32) if clustered else None
     for s in range(0, n, chunk):
         c = min(chunk, n - s)
         x = rng.standard_normal((c, dim), dtype=np.float32)
@@ -133,10 +150,11 @@ def recall_of(got, gt, tk):
 
 
 class Pipeline:
-    """One index + resident query batches + the step function of the timed region."""
+    """One index + query batches (pinned host copies and resident device copies) + the step of the timed region."""
 
     def __init__(self, args, torch, dev, rank, world, sharded, clustered, n, label):
         from minivectordb_amd import HipBridge, derive_search_params, resolve_preset
+        from minivectordb_amd.distributed import block_bytes
         from minivectordb_amd.pipeline import ResidentSearcher
         self.args, self.torch, self.dev, self.rank, self.world, self.sharded = args, torch, dev, rank, world, sharded
         self.preset = resolve_preset(args.preset)
@@ -171,9 +189,17 @@ class Pipeline:
         self.q_host = make_queries(self.nb, self.nq, self.dim, q_seed, self.base, clustered)
         self.q_dev = torch.from_numpy(self.q_host).to(dev)
         self.bridge.setVisitedMode(args.visited_mode)
-        self.searcher = ResidentSearcher(self.bridge, self.nq, self.tk, dev)
+        self.searcher = s = ResidentSearcher(self.bridge, self.nq, self.tk, dev)
+        # the host side of a step ("H2D/D2H of queries/results included"): pinned query batches,
+        # one device staging buffer and one pinned result block per batch in flight
+        self.D = D = max(args.in_flight, 1)
+        if D >= 2:
+            s._pipe_init(self.nq, self.dim, int(self.ann_k), D)
+        self.q_pin = torch.from_numpy(self.q_host).pin_memory()
+        self.stage = [torch.empty((self.nq, self.dim), dtype=torch.float32, device=dev) for _ in range(D)]
+        self.out_pin = [torch.empty(block_bytes(self.nq, self.tk), dtype=torch.uint8).pin_memory() for _ in range(D)]
+        self.out_i = 0
         self.step_i = 0
-        self.events = []
 
     # -- reference pass: per-batch results (single stream) and work counters
     def reference_pass(self):
@@ -192,49 +218,77 @@ class Pipeline:
                       for c in self.ctr]
         self.b_rerank = [int((c[:, 3] * self.dim * 4 + self.dim * 4 + self.tk * 8).sum()) for c in self.ctr]
 
-    def step(self, exchange=True, record=False):
-        a, s = self.args, self.searcher
+    def step(self, exchange=True, host_io=True):
+        """One batch.  host_io: the queries start in pinned host memory and the results end there (both copies on
+        the batch's stream); otherwise the resident device copy of the batch is used and results stay in HBM."""
+        a, s, torch = self.args, self.searcher, self.torch
         i = self.step_i % self.nb
         self.step_i += 1
-        q = self.q_dev[i]
-        if a.in_flight >= 2:
-            slot, ids, l2, n = s.submit_interleaved(q, self.ef_search, self.ann_k, sync_with_current=False, depth=a.in_flight)
-            if record:
-                ev = self.torch.cuda.Event(enable_timing=True)
-                ev.record(s._b_streams[slot])
-                self.events.append(ev)
-            if not (self.sharded and exchange):
+        shard_io = self.sharded and exchange
+        if self.D >= 2:
+            slot = s._pipe_i % self.D
+            S = s._b_streams[slot]
+            q = self.q_dev[i]
+            if host_io:
+                q = self.stage[slot]
+                with torch.cuda.stream(S):   # stream order: the batch that used this staging buffer is D steps back on S
+                    q.copy_(self.q_pin[i], non_blocking=True)
+            sl, *_ = s.submit_interleaved(q, self.ef_search, self.ann_k, sync_with_current=False, depth=self.D)
+            assert sl == slot
+            if not shard_io:
+                if host_io:
+                    with torch.cuda.stream(S):
+                        self.out_pin[slot].copy_(s.slot_block(slot).buf, non_blocking=True)
                 return slot, i
             s.wait(slot)
             block = s.slot_block(slot)
         else:
-            ids, l2, n = s.query_many(q, self.ef_search, self.ann_k)
-            if record:
-                ev = self.torch.cuda.Event(enable_timing=True)
-                ev.record()
-                self.events.append(ev)
-            if not (self.sharded and exchange):
+            q = self.q_dev[i]
+            if host_io:
+                q = self.stage[0]
+                q.copy_(self.q_pin[i], non_blocking=True)
+            s.query_many(q, self.ef_search, self.ann_k)
+            if not shard_io:
+                if host_io:
+                    self.out_pin[0].copy_(s.out_block.buf, non_blocking=True)
                 return -1, i
             slot, block = -1, s.out_block
         from minivectordb_amd.distributed import sharded_exchange
         self.merged = sharded_exchange(block, self.id_offset, lambda full: s.merge_blocks(full, self.nq))
+        if host_io:
+            self.out_pin[self.out_i % self.D].copy_(self.merged.buf, non_blocking=True)
+            self.out_i += 1
         if slot >= 0:
             s.release(slot)  # the all-gather above is the last reader of this slot's block
         return slot, i
 
-    def timed(self, steps, exchange=True, record=False):
-        """barrier + sync | steps | drain + sync + barrier -> seconds (max over ranks)."""
+    def _mark(self):
+        """An event on every stream a step may use: the latest of them = 'everything submitted so far is done'."""
+        torch = self.torch
+        evs = []
+        streams = [torch.cuda.current_stream(self.dev)] + (list(self.searcher._b_streams) if self.D >= 2 else [])
+        for st in streams:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            evs.append(e)
+        return evs
+
+    def timed(self, steps, exchange=True, host_io=True, window=0):
+        """barrier + sync | steps | drain + sync + barrier -> seconds (max over ranks).  window > 0: also the
+        durations of consecutive windows of `window` steps, from stream events (no drain between windows)."""
         import torch.distributed as dist
         torch, dev = self.torch, self.dev
-        self.events = []
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        marks = [self._mark()] if window > 0 else []
         t0 = time.perf_counter()
         last = []
-        for _ in range(steps):
-            last.append(self.step(exchange, record))
-        if self.args.in_flight >= 2:
+        for j in range(steps):
+            last.append(self.step(exchange, host_io))
+            if window > 0 and (j + 1) % window == 0:
+                marks.append(self._mark())
+        if self.D >= 2:
             self.searcher.drain()
         torch.cuda.synchronize(dev)
         if self.world > 1:
@@ -245,13 +299,20 @@ class Pipeline:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         self.last_steps = last
+        self.window_ms = []
+        if window > 0:
+            base = marks[0][0]
+            t = [max(base.elapsed_time(e) for e in m) for m in marks]
+            self.window_ms = [t[k + 1] - t[k] for k in range(len(t) - 1)]
         return el
 
-    def check_last_steps(self):
-        """Overlapped batches must return the bits of the one-at-a-time reference pass."""
-        torch, s, D = self.torch, self.searcher, self.args.in_flight
+    def check_last_steps(self, host_io=True):
+        """Overlapped batches (and their copies in pinned host memory) must be the bits of the one-at-a-time
+        reference pass."""
+        torch, s = self.torch, self.searcher
         if self.sharded:
             return
+        from minivectordb_amd.distributed import TopkBlock
         seen = set()
         for slot, i in reversed(self.last_steps):
             if slot in seen:
@@ -261,53 +322,12 @@ class Pipeline:
             r_ids, r_l2, r_n = self.ref[i]
             assert torch.equal(blk.ids[:self.nq], r_ids) and torch.equal(blk.l2[:self.nq], r_l2) and \
                 torch.equal(blk.n[:self.nq], r_n), "overlapped and one-at-a-time results differ"
-            if D < 2:
+            if host_io:
+                hb = TopkBlock(self.nq, self.tk, buf=self.out_pin[max(slot, 0)])
+                assert torch.equal(hb.ids, r_ids.cpu()) and torch.equal(hb.l2, r_l2.cpu()) and \
+                    torch.equal(hb.n, r_n.cpu()), "results copied to the host differ from the reference pass"
+            if self.D < 2:
                 break
-
-    def median_interval_ms(self):
-        if len(self.events) < 3:
-            return None
-        self.torch.cuda.synchronize(self.dev)
-        # batches on different streams may complete out of submission order: sort the completion times first
-        # and with D batches in flight they complete in clumps: the step time is the median over windows of D
-        # consecutive completions, (t[j + D] - t[j]) / D
-        t = sorted(self.events[0].elapsed_time(e) for e in self.events)
-        D = max(self.args.in_flight, 1)
-        if len(t) <= D:
-            return None
-        gaps = sorted((t[j + D] - t[j]) / D for j in range(len(t) - D))
-        return float(gaps[len(gaps) // 2])
-
-    def pcie_inclusive(self, steps):
-        """Steps that start from pinned host queries and end with the results in pinned host memory."""
-        torch, dev, s, a = self.torch, self.dev, self.searcher, self.args
-        D = max(a.in_flight, 2)
-        qh = torch.from_numpy(self.q_host).pin_memory()
-        stage = [torch.empty((self.nq, self.dim), dtype=torch.float32, device=dev) for _ in range(D)]
-        from minivectordb_amd.distributed import block_bytes
-        outs = [torch.empty(block_bytes(self.nq, self.tk), dtype=torch.uint8).pin_memory() for _ in range(D)]
-        s._pipe_init(self.nq, self.dim, int(self.ann_k), D)
-
-        def one(j):
-            slot = s._pipe_i % D
-            S = s._b_streams[slot]
-            with torch.cuda.stream(S):
-                stage[slot].copy_(qh[j % self.nb], non_blocking=True)
-            sl, *_ = s.submit_interleaved(stage[slot], self.ef_search, self.ann_k, sync_with_current=False, depth=D)
-            assert sl == slot
-            with torch.cuda.stream(S):
-                outs[slot].copy_(s.slot_block(slot).buf, non_blocking=True)
-
-        for j in range(3):
-            one(j)
-        s.drain()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for j in range(steps):
-            one(j)
-        s.drain()
-        torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0
 
     def host_slots(self, steps):
         """The path a host without device pointers uses (Node N-API, plain C): mvdb_query_many_submit / _wait on
@@ -342,7 +362,6 @@ class Pipeline:
 
     def recall(self):
         """recall@10 of batch 0 against the exact float32 top-10 (over ALL shards when sharded)."""
-        import torch.distributed as dist
         from minivectordb_amd.distributed import TopkBlock, gather_blocks, merge_blocks_host
         torch, dev = self.torch, self.dev
         qn, _ = self.bridge.prepareQueries(self.q_host[0])
@@ -352,7 +371,7 @@ class Pipeline:
                                                                torch.full((self.nq,), self.tk, dtype=torch.int32))
             gt_i = torch.from_numpy(merge_blocks_host(gather_blocks(blk.buf), self.nq, self.tk)[0])
             self.step_i = 0
-            self.step(exchange=True)
+            self.step(exchange=True, host_io=False)
             torch.cuda.synchronize(dev)
             got = self.merged.ids.cpu().numpy()
         else:
@@ -363,11 +382,11 @@ class Pipeline:
         self.bridge.close()
 
 
-def cpu_baseline_leg(pl, args):
+def cpu_baseline_leg(pl, args, sample):
     """The C oracle (restatement of the WASM path) on the first queries of batch 0, same dump."""
     from oracle import oracle as O
     p = pl.preset
-    ns = min(args.cpu_sample, pl.nq)
+    ns = min(sample, pl.nq)
     ix = O.OracleIndex(pl.dim, p["m"], p["ef_construction"], 8, seed=1)
     t0 = time.time()
     assert ix.load_bytes(pl.bridge.saveBytes()), "oracle rejected the engine's dump"
@@ -380,22 +399,27 @@ def cpu_baseline_leg(pl, args):
     same = bool(np.array_equal(o_ids, g_ids) and np.array_equal(o_n, g_n) and
                 np.array_equal(o_l2.view(np.uint64), g_l2.view(np.uint64)) and
                 np.array_equal(octr["n_dist"], pl.ctr[0][:ns, 0]))
+    # all-cores figure: the oracle's threads each take a contiguous slice of the queries (independent searches on the
+    # shared read-only dump); timed on enough queries to give every thread a few (not the reference's mode: its
+    # searchMany is one sequential loop)
     nthr = max(1, min(args.build_threads, os.cpu_count() or 1))
+    nmt = min(pl.nq, max(ns, 8 * nthr))
     t0 = time.perf_counter()
-    O.search_many_db(ix, q, pl.base, args.topk, args.preset, threads=nthr)
+    O.search_many_db(ix, pl.q_host[0][:nmt], pl.base, args.topk, args.preset, threads=nthr)
     cpu_mt_s = time.perf_counter() - t0
     ix.close()
     return dict(value=round(ns / cpu_s, 2), unit="queries/s", cores=1, kind="port",
                 sample=f"first {ns} of the {pl.nq} queries of batch 0, full searchMany pipeline on the same "
                        f"{pl.n}-node dump (C restatement of the WASM path; 1 thread = the reference's sequential loop)",
-                all_cores=dict(value=round(ns / cpu_mt_s, 2), cores=nthr),
+                all_cores=dict(value=round(nmt / cpu_mt_s, 2), cores=nthr, queries=nmt,
+                               what="the same oracle, queries split over host threads (not a mode the reference has)"),
                 gpu_matches_oracle_on_sample=same)
 
 
 def traffic_record(pl, kernel):
     """HBM bytes per traversal launch from the committed PMC passes of THIS workload (profiles/), if any."""
     name = f"pmc_traffic_{pl.n // 1_000_000}m_{pl.args.preset}.json"
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         f = os.path.join(ROOT, "profiles", rnd, name)
         if pl.n % 1_000_000 == 0 and pl.dim == 384 and pl.nq == 1000 and not pl.clustered and os.path.exists(f):
             with open(f) as fh:
@@ -405,38 +429,35 @@ def traffic_record(pl, kernel):
     return None, None
 
 
-def run_hnsw(args, torch, dist, dev, rank, world):
-    sharded = world > 1 and args.mode != "replicas"
-    pl = Pipeline(args, torch, dev, rank, world, sharded, False, args.n, "iid")
-    bridge, s = pl.bridge, pl.searcher
-    log(f"rank {rank}: reference pass over {pl.nb} distinct batches (first call uploads the index)")
-    pl.reference_pass()
-    for _ in range(args.warmup):
+def measure(pl, args, steps, warmup, sustain_s, solo):
+    """Warm up, time `steps` host-to-host steps, and price the traversal launches of that region."""
+    torch, dev, s, bridge = pl.torch, pl.dev, pl.searcher, pl.bridge
+    world, sharded = pl.world, pl.sharded
+    for _ in range(warmup):
         pl.step()
-    if args.in_flight >= 2:
+    if pl.D >= 2:
         s.drain()
     torch.cuda.synchronize(dev)
     bridge._L.mvdb_enable_timing(bridge.handle, 1)
-    for st in (0, 1, 2):
+    for st in (0, 1, 2, 4):
         s.stage_stats(st)
     pl.step_i = 0
-    elapsed = pl.timed(args.steps, record=True)
+    elapsed = pl.timed(steps)
     bridge._L.mvdb_enable_timing(bridge.handle, 0)
     s.check()
     pl.check_last_steps()
-    median_ms = pl.median_interval_ms()
-    ms_per_step = elapsed / args.steps * 1e3
     per_step_queries = pl.nq * (world if (world > 1 and not sharded) else 1)
-    qps = per_step_queries / (elapsed / args.steps)
+    res = dict(value=round(per_step_queries / (elapsed / steps), 2), ms_per_step=round(elapsed / steps * 1e3, 4))
 
     # ---- roofline of the dominant kernel (traversal): live HIP-event timing of the timed launches only
     n_launch, trav_ms_total = s.stage_stats(1)
     _, rerank_ms_total = s.stage_stats(2)
     _, prep_ms_total = s.stage_stats(0)
-    bytes_timed = sum(pl.b_ann[j % pl.nb] for j in range(args.steps))
-    rerank_bytes_timed = sum(pl.b_rerank[j % pl.nb] for j in range(args.steps))
+    n_replay, replay_ms_total = s.stage_stats(4)
+    bytes_timed = sum(pl.b_ann[j % pl.nb] for j in range(steps))
+    rerank_bytes_timed = sum(pl.b_rerank[j % pl.nb] for j in range(steps))
     trav_ms = trav_ms_total / max(n_launch, 1)
-    bytes_per_launch = bytes_timed / max(args.steps, 1)
+    bytes_per_launch = bytes_timed / max(steps, 1)
     achieved = bytes_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
     m0 = 2 * pl.preset["m"]
     kernel = ("traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else
@@ -446,7 +467,8 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(bytes_per_launch), avg_launch_ms=round(trav_ms, 4),
                     launches_timed=int(n_launch),
-                    rerank_bytes_per_launch=int(rerank_bytes_timed / max(args.steps, 1)),
+                    replay_avg_launch_ms=round(replay_ms_total / max(n_replay, 1), 4),
+                    rerank_bytes_per_launch=int(rerank_bytes_timed / max(steps, 1)),
                     rerank_avg_launch_ms=round(rerank_ms_total / max(n_launch, 1), 4),
                     prep_avg_launch_ms=round(prep_ms_total / max(n_launch, 1), 4),
                     # launches overlap when several batches are in flight: `achieved` (per launch, by the
@@ -454,13 +476,11 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                     effective_gbs=round(bytes_timed / elapsed / 1e9, 2),
                     effective_frac=round(bytes_timed / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                     pipeline_gbs=round((bytes_timed + rerank_bytes_timed) / elapsed / 1e9, 2))
-
-    extras = {}
-    if not sharded:
+    if solo and not sharded:
         # the same kernel with one batch at a time: what one launch achieves when it has the chip to itself
         bridge._L.mvdb_enable_timing(bridge.handle, 1)
         s.stage_stats(1)
-        k_solo = min(max(args.steps, 8), 2 * pl.nb)
+        k_solo = min(max(steps, 8), 2 * pl.nb)
         for j in range(k_solo):
             s.query_many(pl.q_dev[j % pl.nb], pl.ef_search, pl.ann_k)
         torch.cuda.synchronize(dev)
@@ -471,46 +491,81 @@ def run_hnsw(args, torch, dist, dev, rank, world):
             solo_bytes = sum(pl.b_ann[j % pl.nb] for j in range(k_solo)) / k_solo
             roofline["solo_avg_launch_ms"] = round(solo_ms, 4)
             roofline["solo_frac"] = round(solo_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    res["roofline"] = roofline
+    # the same steps with queries and results resident in HBM (no copies in the step)
+    el = pl.timed(steps, host_io=False)
+    pl.check_last_steps(host_io=False)
+    res["resident"] = dict(value=round(per_step_queries / (el / steps), 2), unit="queries/s",
+                           ms_per_step=round(el / steps * 1e3, 4),
+                           what="the same steps on query batches already in HBM, results left in HBM")
+    if sustain_s > 0:
+        # >= 10 windows of >= 20 steps; window durations from stream events, no drain between windows
+        nw = 12
+        w = max(20, int(math.ceil(sustain_s / max(elapsed / steps, 1e-6) / nw)))
+        el = pl.timed(nw * w, window=w)
+        wm = sorted(x / w for x in pl.window_ms)
+        res["sustained"] = dict(value=round(per_step_queries / (el / (nw * w)), 2), unit="queries/s", steps=nw * w,
+                                seconds=round(el, 3), windows=len(wm), steps_per_window=w,
+                                median_window_ms_per_step=round(wm[len(wm) // 2], 4),
+                                min_window_ms_per_step=round(wm[0], 4), max_window_ms_per_step=round(wm[-1], 4))
+        s.check()
+    return res
+
+
+def run_hnsw(args, torch, dist, dev, rank, world):
+    t_start = time.time()
+    sharded = world > 1 and args.mode != "replicas"
+    legs = set() if args.legs == "none" else set(args.legs.split(","))
+    if "auto" in legs:
+        legs = {"clustered", "scan", "10m"} if (world == 1 and args.n == 1_000_000 and args.dim == 384) else \
+            ({"clustered"} if (world == 1 and args.n <= 2_000_000) else set())
+    pl = Pipeline(args, torch, dev, rank, world, sharded, False, args.n, "iid")
+    bridge, s = pl.bridge, pl.searcher
+    build_per_rank = [round(pl.build_s, 2)]
+    if world > 1:
+        bt = torch.tensor([pl.build_s], dtype=torch.float64, device=dev)
+        allb = [torch.zeros_like(bt) for _ in range(world)]
+        dist.all_gather(allb, bt)
+        build_per_rank = [round(float(x.item()), 2) for x in allb]
+        log(f"rank {rank}: index build seconds per rank {build_per_rank}")
+    log(f"rank {rank}: reference pass over {pl.nb} distinct batches (first call uploads the index)")
+    pl.reference_pass()
+    res = measure(pl, args, args.steps, args.warmup, args.sustain_s, solo=True)
+    roofline = res["roofline"]
+
+    extras = {"resident": res["resident"]}
+    if "sustained" in res:
+        extras["sustained"] = res["sustained"]
     if world > 1 and sharded:  # the same ranks with no exchange: what "replicas" scaling would show
         el = pl.timed(args.steps, exchange=False)
         extras["replicas"] = dict(value=round(world * pl.nq / (el / args.steps), 2), unit="queries/s",
                                   mode="every rank answers its own copy of the batch on its own index, no exchange "
                                        "(embarrassingly parallel; says nothing about the sharded path)")
     if world == 1 and not args.no_pcie:
-        el = pl.pcie_inclusive(args.steps)
-        extras["pcie_inclusive"] = dict(value=round(pl.nq / (el / args.steps), 2), unit="queries/s",
-                                        ms_per_step=round(el / args.steps * 1e3, 4),
-                                        what="each step copies its queries from pinned host memory and its results back")
-        s.check()
-        if not sharded:
-            el, same = pl.host_slots(args.steps)
-            extras["host_slots"] = dict(value=round(pl.nq / (el / args.steps), 2), unit="queries/s",
-                                        ms_per_step=round(el / args.steps * 1e3, 4), same_as_device_path=same,
-                                        what="mvdb_query_many_submit/_wait on pageable host buffers (the Node / plain C "
-                                             "host's way to keep batches in flight), copies inside")
-    if args.sustain_s > 0:
-        k = max(args.steps, int(math.ceil(args.sustain_s / max(elapsed / args.steps, 1e-6))))
-        el = pl.timed(k)
-        extras["sustained"] = dict(value=round(per_step_queries / (el / k), 2), unit="queries/s", steps=k,
-                                   seconds=round(el, 3))
-        s.check()
-
+        el, same = pl.host_slots(args.steps)
+        extras["host_slots"] = dict(value=round(pl.nq / (el / args.steps), 2), unit="queries/s",
+                                    ms_per_step=round(el / args.steps * 1e3, 4), same_as_device_path=same,
+                                    what="mvdb_query_many_submit/_wait on pageable host buffers (the Node / plain C "
+                                         "host's way to keep batches in flight), copies inside")
     recall = None if args.no_recall else pl.recall()
     if world > 1 and rank != 0:
         recall = None
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        cpu_baseline = cpu_baseline_leg(pl, args)
+        cpu_baseline = cpu_baseline_leg(pl, args, args.cpu_sample if pl.n <= 2_000_000 else min(args.cpu_sample, 64))
 
     ctr_all = np.concatenate(pl.ctr, 0)
     out = None
     if rank == 0:
         p = pl.preset
+        sus = res.get("sustained")
         out = dict(metric="searchMany QPS @ recall@10 (topK=10, 384-d int8+f32 rerank)",
-                   value=round(qps, 2), unit="queries/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   value=res["value"], unit="queries/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="i8", dtype_detail="int8 rows, exact i32 distances (traversal); f32 rows, f64 accumulate (rerank)",
                    data="synthetic",
+                   value_includes="H2D of each query batch from pinned host memory and D2H of its result block "
+                                  "(SURVEY.md 8d); `resident` = the same steps without the copies",
                    config=dict(workload=f"{pl.n}x{pl.dim} int8 HNSW (preset {args.preset}: M={p['m']}, efc="
                                         f"{p['ef_construction']}, ef=annK={pl.ann_k}) + f32 rerank, batch {pl.nq} "
                                         f"queries, topK={pl.tk}" + (f", {world} id-range shards of {pl.n}" if sharded else ""),
@@ -520,37 +575,84 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                                batches=(f"{args.in_flight} in flight: batch i on stream i % {args.in_flight}"
                                         if args.in_flight >= 2 else "one at a time"),
                                distinct_query_batches=pl.nb, f32_store=("pinned host" if args.host_f32 else "HBM"),
-                               graph=pl.graph, build_seconds=round(pl.build_s, 2), build=pl.build_stats,
+                               graph=pl.graph, build_seconds=round(pl.build_s, 2), build_seconds_per_rank=build_per_rank,
+                               build=pl.build_stats,
                                exchange=("one packed all-gather of per-shard top-k blocks per batch + (l2,id) merge kernel"
                                          if sharded else None)),
-                   median_ms_per_step=None if median_ms is None else round(median_ms, 4),
+                   median_ms_per_step=None if sus is None else sus["median_window_ms_per_step"],
+                   median_of=None if sus is None else f"{sus['windows']} consecutive windows of {sus['steps_per_window']} steps of the sustained loop",
                    recall_at_10=None if recall is None else round(recall, 4),
                    roofline=roofline, cpu_baseline=cpu_baseline,
                    counters=dict(mean_n_dist=float(ctr_all[:, 0].mean()), mean_n_l0lists=float(ctr_all[:, 1].mean()),
-                                 mean_n_upperlists=float(ctr_all[:, 2].mean())))
+                                 mean_n_upperlists=float(ctr_all[:, 2].mean())),
+                   lean_fallbacks=bridge.leanFallbacks())
         out.update(extras)
     pl.close()
-    del pl
+    del pl, s, bridge
+    torch.cuda.empty_cache()
 
     # ---- second synthetic set with neighbourhood structure (the i.i.d. line above stays the headline)
-    if world == 1 and args.second_dataset != "none" and (args.second_dataset == "clustered" or args.n <= 2_000_000):
+    if "clustered" in legs and world == 1:
         p2 = Pipeline(args, torch, dev, rank, world, False, True, args.n, "clustered")
         p2.reference_pass()
-        for _ in range(args.warmup):
-            p2.step()
-        p2.searcher.drain() if args.in_flight >= 2 else None
-        p2.step_i = 0
-        el = p2.timed(args.steps)
-        p2.searcher.check()
-        p2.check_last_steps()
+        r2 = measure(p2, args, args.steps, args.warmup, min(args.sustain_s, 1.0), solo=False)
         c2 = np.concatenate(p2.ctr, 0)
+        rf2 = r2["roofline"]
+        rec2 = None if args.no_recall else round(p2.recall(), 4)
         out["second_dataset"] = dict(
             data=f"{CLUSTERS} Gaussian clusters (centres N(0,1), sigma {CLUSTER_SIGMA}), queries = stored points + noise",
-            value=round(p2.nq / (el / args.steps), 2), unit="queries/s", ms_per_step=round(el / args.steps * 1e3, 4),
-            recall_at_10=None if args.no_recall else round(p2.recall(), 4), build_seconds=round(p2.build_s, 2),
+            value=r2["value"], unit="queries/s", ms_per_step=r2["ms_per_step"], resident=r2["resident"]["value"],
+            sustained=r2.get("sustained", {}).get("value"), recall_at_10=rec2, build_seconds=round(p2.build_s, 2),
             mean_n_dist=float(c2[:, 0].mean()), mean_n_l0lists=float(c2[:, 1].mean()),
-            effective_gbs=round(sum(p2.b_ann[j % p2.nb] for j in range(args.steps)) / el / 1e9, 2))
+            frac=rf2["frac"], avg_launch_ms=rf2["avg_launch_ms"], effective_gbs=rf2["effective_gbs"],
+            effective_frac=rf2["effective_frac"], algorithmic_bytes_per_launch=rf2["algorithmic_bytes_per_launch"])
+        # the same per-launch definition as `frac`, on the set where the index has neighbourhoods to find
+        out["roofline"]["frac_structured"] = rf2["frac"]
+        out["roofline"]["structured"] = dict(value=r2["value"], unit="queries/s", recall_at_10=rec2,
+                                             effective_frac=rf2["effective_frac"], avg_launch_ms=rf2["avg_launch_ms"])
         p2.close()
+        del p2
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE configs[2] on the same line: exact int8 scan, 1 M x 512, 4096 queries
+    if "scan" in legs and world == 1:
+        import copy
+        a2 = copy.copy(args)
+        a2.n, a2.dim, a2.nq, a2.second_dataset, a2.cpu_sample = 1_000_000, 512, 4096, "none", min(args.cpu_sample, 16)
+        sc = run_scan(a2, torch, dist, dev, rank, world)
+        out["scan_1m_512"] = dict(metric=sc["metric"], value=sc["value"], unit=sc["unit"], ms_per_step=sc["ms_per_step"],
+                                  steps=sc["steps"], workload=sc["config"]["workload"], roofline=sc["roofline"],
+                                  hnsw_recall_vs_exact_int8=sc["hnsw_recall_vs_exact_int8"], cpu_baseline=sc["cpu_baseline"])
+        torch.cuda.empty_cache()
+
+    # ---- the north-star size: 10 M x 384 balanced on one GPU
+    if "10m" in legs and world == 1:
+        spent = time.time() - t_start
+        if spent > args.leg_deadline_s:
+            out["north_star_10m"] = dict(skipped=f"{spent:.0f}s already spent (limit {args.leg_deadline_s}s before this leg)")
+        else:
+            import copy
+            a3 = copy.copy(args)
+            a3.n = 10_000_000
+            p3 = Pipeline(a3, torch, dev, rank, world, False, False, a3.n, "10m")
+            p3.reference_pass()
+            r3 = measure(p3, a3, args.steps, args.warmup, min(args.sustain_s, 1.0), solo=True)
+            rec3 = None if args.no_recall else round(p3.recall(), 4)
+            cpu3 = cpu_baseline_leg(p3, a3, min(args.cpu_sample, 64)) if args.cpu_sample > 0 else None
+            c3 = np.concatenate(p3.ctr, 0)
+            out["north_star_10m"] = dict(
+                workload=f"{p3.n}x{p3.dim} int8 HNSW (preset {args.preset}, ef=annK={p3.ann_k}) + f32 rerank, batch "
+                         f"{p3.nq} queries, topK={p3.tk}",
+                value=r3["value"], unit="queries/s", ms_per_step=r3["ms_per_step"], steps=args.steps,
+                resident=r3["resident"]["value"], sustained=r3.get("sustained"), recall_at_10=rec3,
+                roofline=r3["roofline"], cpu_baseline=cpu3, build_seconds=round(p3.build_s, 2), build=p3.build_stats,
+                mean_n_dist=float(c3[:, 0].mean()),
+                lean_fallbacks=p3.bridge.leanFallbacks())
+            p3.close()
+            del p3
+            torch.cuda.empty_cache()
+    if out is not None:
+        out["bench_seconds"] = round(time.time() - t_start, 1)
     return out
 
 
@@ -681,7 +783,13 @@ def main():
     ap.add_argument("--no-pcie", action="store_true")
     ap.add_argument("--batches", type=int, default=8, help="distinct query batches rotated through the steps")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of the sustained leg (0 = skip)")
-    ap.add_argument("--second-dataset", default="auto", choices=["auto", "none", "clustered"])
+    ap.add_argument("--second-dataset", default="auto", choices=["auto", "none", "clustered"],
+                    help="scan workload only: also run the scan on the clustered set")
+    ap.add_argument("--legs", default="auto",
+                    help="extra legs of the hnsw line: comma list of clustered,scan,10m | none | auto (= all three "
+                         "for the default 1M x 384 single-GPU run, clustered for other sizes up to 2M)")
+    ap.add_argument("--leg-deadline-s", type=float, default=330.0,
+                    help="the 10m leg is skipped when the run has already taken this long")
     ap.add_argument("--host-f32", action="store_true", help="float32 store in pinned host memory (preloadVectors=false)")
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")

@@ -344,9 +344,7 @@ struct mvdb_index {
 		DevBuf adm_log, adm_n, flag;   // traverse_lean_kernel -> replay_kernel
 		bool vis_clean = false;        // the first vis_clean_bytes of `visited` are zero (log mode leaves them so)
 		size_t vis_clean_bytes = 0;
-		void *vis_seen_ptr = nullptr;  // the allocation (pointer, capacity) `vis_epoch` counts launches of
-		size_t vis_seen_cap = 0;
-		unsigned vis_epoch = 0;        // stamp of the last launch on `visited` (VisitedSet): 1..255
+		void *vis_seen_ptr = nullptr;  // the allocation `vis_clean` speaks of
 	} ss[kStreamSets];
 	int ss_next = 0;  // round-robin victim when every set is taken
 	// Host slots (mvdb_query_many_submit / _wait): a stream of its own, pinned host staging and device
@@ -1069,7 +1067,6 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	a.results_cap = h->g.results_cap;
 	a.set_only = set_only ? 1 : 0;
 	a.vis_stride = visited_stride_bytes(h->g.max_elements);
-	a.epoch = 1;
 	a.vis_log = nullptr;  // memset mode unless the caller sets a log up
 	a.vis_log_cap = 0;
 	a.adm_log = nullptr;  // lean path only (search_many_dev_impl)
@@ -1129,7 +1126,7 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	}
 	// bitmap clean-up: per-launch memset, or the kernel's own log-and-clear (VisitedLog) for large indexes
 	const bool lean = traverse_use_lean(h, a);  // the lean kernel always works on a bitmap the launcher zeroed
-	const bool log_mode = !MVDB_VISITED_STAMPS && h->visited_mode == 2 && !lean;
+	const bool log_mode = h->visited_mode == 2 && !lean;
 	a.vis_log = nullptr;
 	a.vis_log_cap = h->visited_log_cap > 0 ? h->visited_log_cap : kVisitedLogCap;
 	if (log_mode) {
@@ -1147,7 +1144,7 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	a.only_flagged = nullptr;
 	if (lean) {
 		a.adm_log_cap = h->lean_log_cap > 0 ? h->lean_log_cap : 12 * a.ef + 1024;
-		const size_t per_q = (size_t)a.adm_log_cap * sizeof(uint2);
+		const size_t per_q = (size_t)(a.adm_log_cap + 64) * sizeof(uint2);  // + 64: where masked-off lanes of a log store write
 		slab = (int)std::min<size_t>((size_t)slab, std::max<size_t>(1, ((size_t)2 << 30) / per_q));  // <= 2 GiB of logs per stream
 		a.adm_log = static_cast<uint2 *>(sc->adm_log.need((size_t)slab * per_q));
 		a.adm_n = static_cast<int *>(sc->adm_n.need((size_t)slab * 4));
@@ -1168,16 +1165,11 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 				sc->vis_clean = true;
 				sc->vis_clean_bytes = need;
 			}
-		} else if (!MVDB_VISITED_STAMPS || sc->vis_seen_ptr != vis || sc->vis_seen_cap != sc->visited.cap || sc->vis_epoch >= 255) {
-			// a fresh allocation, or the epoch wrapping after 255 launches, clears the whole buffer; otherwise the
-			// next epoch makes every stamp of earlier launches read as "not visited" (nothing to clear per batch)
-			HIP_OK(h, hipMemsetAsync(vis, 0, MVDB_VISITED_STAMPS ? sc->visited.cap : need, s));
+		} else {
+			HIP_OK(h, hipMemsetAsync(vis, 0, need, s));
 			sc->vis_seen_ptr = vis;
-			sc->vis_seen_cap = sc->visited.cap;
-			sc->vis_epoch = 0;
 			sc->vis_clean = false;  // the launch leaves its marks behind
 		}
-		a.epoch = ++sc->vis_epoch;
 		a.q = d_q + (size_t)q0 * g.cfg.dim;
 		a.nq = n;
 		a.visited = vis;
@@ -1287,7 +1279,6 @@ int mvdb_search_many_dev_noalloc(mvdb_index *h, const int8_t *d_q, int nq, int k
 	}
 	void *vis = g_scratch_ptr[d];                // never the array's name: that is not a device address
 	HIP_OK(h, hipMemsetAsync(vis, 0, need, s));  // the array keeps the last call's bits: cleared every call
-	a.epoch = 1;
 	a.q = d_q;
 	a.nq = nq;
 	a.visited = vis;
@@ -1679,12 +1670,6 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.nodes_per_split = 0;
 	a.level0 = kScanLevel0;
 	a.level_ratio = kScanLevelRatio;
-#ifdef MVDB_SCAN_TUNE  // experiments only (tools/scan_bench.py); the shipped library has no such knob
-	if (const char *e = getenv("MVDB_SCAN_SEED")) a.seed = atoi(e) != 0 ? 1 : 0;
-	if (const char *e = getenv("MVDB_SCAN_WIDE")) a.wide = k <= kWideMaxK ? std::max(0, atoi(e)) : 0;  // 1: every level
-	if (const char *e = getenv("MVDB_SCAN_LEVEL0")) a.level0 = std::max(64, atoi(e) / 64 * 64);
-	if (const char *e = getenv("MVDB_SCAN_RATIO")) a.level_ratio = std::max(2, atoi(e));
-#endif
 	a.qtiles = a.s2 = a.nsplit = 0;  // per level (scan_plan)
 	{
 		ScanLevel plan[kScanMaxLevels];
@@ -1701,11 +1686,6 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.part_n = reinterpret_cast<int32_t *>(part + part_elems * 8);
 	a.thr_g = reinterpret_cast<unsigned long long *>(part + part_bytes);
 	HIP_OK(h, hipMemsetAsync(a.thr_g, 0xff, (size_t)nq * 8, s));
-	a.dbg = nullptr;
-#ifdef MVDB_SCAN_DEBUG
-	a.dbg = static_cast<unsigned long long *>(h->prof_buf.need(128));
-	HIP_OK(h, hipMemsetAsync(a.dbg, 0, 128, s));
-#endif
 	a.out_ids = d_out_ids;
 	a.out_val = d_out_val;
 	a.out_count = d_out_count;
@@ -1786,14 +1766,6 @@ int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, i
 	return 1;
 }
 
-#ifdef MVDB_SCAN_DEBUG
-// diagnostic build only: counters of the last scan launch (tools/scan_debug.py)
-int mvdb_debug_scan_counters(mvdb_index *h, unsigned long long *out)
-{
-	if (!h->prof_buf.p) return 0;
-	return hipMemcpy(out, h->prof_buf.p, 128, hipMemcpyDeviceToHost) == hipSuccess;
-}
-#endif
 #ifdef MVDB_TRAVERSE_PROFILE
 // diagnostic build only: per-query cycle sums of the last traversal launch (nq x 16)
 int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)

@@ -55,7 +55,6 @@ struct ScanArgs {
 	int seed;                // 1: level 0 goes to scan_seed_kernel (see scan_plan)
 	int wide;                // > 0: levels of at least this many nodes go to scan_wide_kernel (k <= kWideMaxK); see scan_plan
 	unsigned long long *thr_g;     // [nq] smallest k-th key published by any split, ~0 before the launch
-	unsigned long long *dbg;       // MVDB_SCAN_DEBUG builds: 8 counters (see tools/scan_debug.py)
 	unsigned long long *part_key;  // [nq][nslots][k]
 	int32_t *part_n;               // [nq][nslots]
 	int32_t *out_ids, *out_val, *out_count;
@@ -123,17 +122,10 @@ __device__ __forceinline__ unsigned long long scan_key(int val, int id)
 // rows, and far enough from both for the differences not to overflow
 constexpr int kScanNoBound = -(1 << 29);
 
-// Staging path.  1 (default): LDS-DMA (global_load_lds_dwordx4): node tiles go HBM/L2 -> LDS without
-// passing through registers, two tiles ahead with three buffers, counted vmcnt + raw s_barrier.
-// 0: through registers (global_load_dwordx4 + ds_write_b128), kept for A/B measurements.
-#ifndef MVDB_SCAN_DMA
-#define MVDB_SCAN_DMA 1
-#endif
-#if MVDB_SCAN_DMA
+// Staging path: LDS-DMA (global_load_lds_dwordx4): node tiles go HBM/L2 -> LDS without passing through
+// registers, two tiles ahead with three buffers, counted vmcnt + raw s_barrier.  (Staging through registers,
+// global_load_dwordx4 + ds_write_b128, was the round-1 path: slower, see DESIGN.md.)
 constexpr int kScanPoll = 16;  // staged tiles between polls of the shared bounds (an ordinary load drains the DMA queue)
-#else
-constexpr int kScanPoll = 4;
-#endif
 // sources of the LDS-DMA lanes that have nothing to fetch: pad slots, pieces past the row, rows past the end
 static __device__ __align__(16) int g_scan_zero[4] = {0, 0, 0, 0};
 static __device__ int g_scan_neg1 = -1;
@@ -159,9 +151,6 @@ __device__ __forceinline__ void scan_wait_vm_upto(int n)
 // 0 (default): the two waves of a SIMD alternate tiles.  1: every wave issues its share of every tile, one
 // instruction at a time between its MFMAs.  Measured the same within 2 % (1 M x 512, 4096 queries): the CU's fill
 // path (~30 B/clk) is paid either as issue time or as barrier time.
-#ifndef MVDB_SCAN_DMA_SPREAD
-#define MVDB_SCAN_DMA_SPREAD 0
-#endif
 
 template <int KS, int METRIC, int CAP>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
@@ -279,47 +268,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 		}
 	};
 
-	// ---- node tile staging: kScanStage rows x KS*64 bytes, KS/2 16-byte pieces per thread, through
-	// registers.  Tile t+D (D = NB-1) is loaded during tile t-1, written to its LDS buffer piece by
-	// piece among the MFMAs of the first pass of tile t -- after the barrier that ended the last
-	// reads of that buffer, so the (slow: ~13 cycles each, one path per CU) ds_write_b128 of the 8
-	// waves overlap the matrix pipe instead of queueing up in front of the barrier -- and the
-	// registers are reloaded for tile t+D+1 at the end of that pass.
-	constexpr int PIECES = KS * 4 * kScanStage / kScanThreads;
-	constexpr int pieces_row = KS * 4;
 	const int row_pieces_valid = ix.row_stride >> 4;
-	int4 stage[PIECES];
-	int stage_norm = -1;
-	auto stage_load_piece = [&](int i, int tile) {
-#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 16)  // timing experiment: every tile re-reads the first two (cache hits)
-		tile &= 1;
-#endif
-		const int node0 = n_begin + tile * kScanStage;
-		const int p = tid + kScanThreads * i;
-		const int r = p / pieces_row, c = p % pieces_row;
-		// no branch around the load (hipcc would wait for it at the next MFMA): rows past the end
-		// re-read the last row and are excluded by their norm (-1); pieces past the row are zeroed
-		// when stored
-		const int node = node0 + r < n_end ? node0 + r : n_end - 1;
-		const int cc = c < row_pieces_valid ? c : 0;
-		stage[i] = *reinterpret_cast<const int4 *>(ix.vec + (size_t)node * (size_t)ix.row_stride + cc * 16);
-		if (i == 0) {
-			const int nn = node0 + (tid & (kScanStage - 1));
-			const int nv = a.norm2[nn < n_end ? nn : n_end - 1];
-			stage_norm = nn < n_end ? nv : -1;
-		}
-	};
-	auto stage_store_piece = [&](int i, int bufi) {
-		unsigned char *dst = btile + (size_t)bufi * kScanStage * ROWB;
-		const int p = tid + kScanThreads * i;
-		const int r = p / pieces_row, c = p % pieces_row;
-		int4 v = stage[i];
-		if (c >= row_pieces_valid) v = make_int4(0, 0, 0, 0);
-		*reinterpret_cast<int4 *>(dst + r * ROWB + (c ^ scan_row_flip(r)) * 16) = v;
-		if (i == 0 && tid < kScanStage) bnorm[bufi * kScanStage + tid] = stage_norm;
-	};
 
-#if MVDB_SCAN_DMA
 	// ---- LDS-DMA staging.  A wave-instruction writes 64 consecutive 16-byte slots of LDS (M0 base +
 	// lane * 16) from per-lane global addresses, so the padded, pair-swapped tile image is filled
 	// slot by slot: slot s = row s / (KS*4+1), position s % (KS*4+1); position p holds piece
@@ -334,23 +284,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 	// faster).  Full tiles of full rows take the short form: uniform base + per-lane offset.
 	constexpr int SLOTS_ROW = KS * 4 + 1;
 	constexpr int DMA_PER_TILE = kScanStage * SLOTS_ROW / 64;
-#if MVDB_SCAN_DMA_SPREAD
-	// every wave issues its share (instructions wave, wave + 8, ...) of every tile, ONE instruction at a time
-	// between the MFMAs of the tile before it (scan_dma_pos), so the CU's fill path (~1 KB per ~36 cycles) never
-	// backs up into the issuing wave
-	constexpr int DMA_WAVES = kScanWaves;
-	const int dma_grp = 0, dma_w = wave;
-#else
 	constexpr int DMA_WAVES = 4;
 	const int dma_grp = wave >> 2, dma_w = wave & 3;
-#endif
 	constexpr int DMA_MAX = (DMA_PER_TILE + DMA_WAVES - 1) / DMA_WAVES;
 	int dma_off[DMA_MAX], dma_row[DMA_MAX];
 	const bool full_rows = row_pieces_valid >= KS * 4;
-	int my_dma = dma_w == DMA_WAVES - 1 ? 1 : 0;  // vector-memory operations this wave issues per tile it fetches
 #pragma unroll
 	for (int i = 0; i < DMA_MAX; i++) {
-		if (dma_w + DMA_WAVES * i < DMA_PER_TILE) my_dma++;
 		const int slot = (dma_w + DMA_WAVES * i) * 64 + lane;
 		const int r = slot / SLOTS_ROW, cpos = slot - r * SLOTS_ROW;
 		const int c = cpos ^ scan_row_flip(r);
@@ -387,26 +327,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 #pragma unroll
 		for (int i = 0; i < DMA_MAX; i++) dma_issue_one(i, tile, bufi);
 	};
-	// spread mode: instruction i of a tile goes out before k-step scan_dma_pos(i) of the 2 * KS k-steps of the tile before
-	auto dma_pos = [&](int i) -> int {
-		const int p = (i * 2 * KS) / DMA_MAX + 1;
-		return p < 2 * KS ? p : 2 * KS - 1;
-	};
-#endif
-
-#ifdef MVDB_SCAN_DEBUG
-	unsigned long long dbg_c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
 	// The (rare) elements that pass the fast test are appended to their row's buffer.  C[row][col]:
 	// col = lane & 15 (node), row = (lane >> 4) * 4 + reg (query) of tile (rt, ct); vn0/vn1 = norms of
 	// this lane's two columns; mg[rt * 2 + ct] = the lane's largest element of that tile; gu = the
 	// bounds these accumulators started from.
 	auto slow_path = [&](const v4i (&acc)[2][2], const int (&mg)[4], const int (&gu)[8], int node0, int vn0, int vn1) {
-#ifdef MVDB_SCAN_DEBUG
-		const unsigned long long t_in = __builtin_amdgcn_s_memtime();
-		dbg_c[1]++;
-#endif
 		unsigned pend = 0;
 #pragma unroll
 		for (int t = 0; t < 4; t++) {
@@ -445,25 +370,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 					}
 				}
 			}
-#ifdef MVDB_SCAN_DEBUG
-			dbg_c[2]++;
-#endif
 			if (__ballot(ovf)) {  // a full buffer keeps its element pending: compact, tighten the bounds, retry
 				const unsigned full = (unsigned)__ballot(owner && cnt[lane & (kScanWR - 1)] >= kScanCap);
-#ifdef MVDB_SCAN_DEBUG
-				dbg_c[3] += __builtin_popcount(full);
-				const unsigned long long t_c = __builtin_amdgcn_s_memtime();
-#endif
 				compact_rows(full);
 				refresh_bounds();
-#ifdef MVDB_SCAN_DEBUG
-				dbg_c[7] += __builtin_amdgcn_s_memtime() - t_c;
-#endif
 			}
 		}
-#ifdef MVDB_SCAN_DEBUG
-		dbg_c[4] += __builtin_amdgcn_s_memtime() - t_in;
-#endif
 	};
 	auto col_init = [&](int vn) -> int { return vn < 0 ? -(1 << 30) : (METRIC == 0 ? -(vn >> 1) : 0); };
 	auto tile_max = [&](const v4i &v) -> int {
@@ -484,27 +396,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 	for (int i = 0; i < 8; i++) gA[i] = gB[i] = kScanNoBound;
 	int pvn0 = -1, pvn1 = -1, pnode0 = 0;
 	unsigned long long ext_next = ~0ull;
-	constexpr int D = NB - 1;  // tiles between a tile's LDS store and its use
-#if MVDB_SCAN_DMA
-#if MVDB_SCAN_DMA_SPREAD
-	for (int t = 0; t < D && t < ntiles; t++) dma_issue(t, t);
-#else
 	for (int t = 0; t < NB && t < ntiles; t++)
 		if ((t & 1) == dma_grp) dma_issue(t, t);
-#endif
 	scan_wait_vm<0>();
-#else
-	for (int t = 0; t < D && t < ntiles; t++) {
-#pragma unroll
-		for (int i = 0; i < PIECES; i++) stage_load_piece(i, t);
-#pragma unroll
-		for (int i = 0; i < PIECES; i++) stage_store_piece(i, t);
-	}
-	if (D < ntiles) {
-#pragma unroll
-		for (int i = 0; i < PIECES; i++) stage_load_piece(i, D);
-	}
-#endif
 	// bounds known before the sweep starts (the levels before this one, or splits that are ahead)
 	if (owner) {
 		if (my_qrow < a.nq) ext = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -532,8 +426,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 	// one MFMA pass over 32 staged rows (half `half` of buffer `cur`) into accN (started from the
 	// bounds gN), with the fast test of the previous pass (accP, started from gP) riding along;
 	// (nbuf, nhalf): the pass whose first fragments are fetched during this one, nbuf < 0: none
-	// st: the staged registers (tile + D) go to buffer `fill` during this pass; ld: they are reloaded (tile + D + 1)
-	auto pass = [&](int tile, int cur, int half, int nbuf, int nhalf, bool st, bool ld, int fill, v4i (&accN)[2][2],
+	auto pass = [&](int tile, int cur, int half, int nbuf, int nhalf, v4i (&accN)[2][2],
 	                int (&gN)[8], const v4i (&accP)[2][2], const int (&gP)[8]) {
 
 		const unsigned char *bp0 = btile + ((size_t)cur * kScanStage + half * kScanTN) * ROWB + frag_off;
@@ -564,64 +457,30 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 		bf[1][1] = pf[1][1];
 #pragma unroll
 		for (int ks = 0; ks < KS; ks++) {
-#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 4)  // timing experiments only: no fragment reads from LDS
-			if (ks + 2 < KS) {
-				bf[ks + 2][0] = bf[ks][1];
-				bf[ks + 2][1] = bf[ks][0];
-				asm volatile("" : "+v"(bf[ks + 2][0]), "+v"(bf[ks + 2][1]));
-			}
-#else
 			if (ks + 2 < KS) {
 				bf[ks + 2][0] = *reinterpret_cast<const v4i *>(bp0 + (ks + 2) * 64);
 				bf[ks + 2][1] = *reinterpret_cast<const v4i *>(bp1 + (ks + 2) * 64);
 			}
 			if (ks == KS - 2 && nbuf >= 0) prefetch(nbuf, nhalf);
-#endif
-#if MVDB_SCAN_DMA && MVDB_SCAN_DMA_SPREAD
-#pragma unroll
-			for (int i = 0; i < DMA_MAX; i++)
-				if (dma_pos(i) == half * KS + ks && tile + D < ntiles) dma_issue_one(i, tile + D, fill);
-#endif
-			// (stores first, then every reload: a reload issued between two stores would make the
-			// next store's vmcnt wait cover it)
-#if (defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 8)) || MVDB_SCAN_DMA  // ... no staging / not through registers
-			if (false) {
-#else
-			if (st && (ks & 1) == 0 && (ks >> 1) < PIECES) stage_store_piece(ks >> 1, fill);
-			if (ld && ks == KS - 1) {
-#endif
-#pragma unroll
-				for (int i = 0; i < PIECES; i++) stage_load_piece(i, tile + D + 1);
-			}
 #pragma unroll
 			for (int rt = 0; rt < 2; rt++) {
 				accN[rt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], bf[ks][0], accN[rt][0], 0, 0, 0);
 				accN[rt][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qf[rt][ks], bf[ks][1], accN[rt][1], 0, 0, 0);
 			}
 		}
-#if defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 2)  // timing experiments only (wrong results; bit flags): no fast test
-		asm volatile("" ::"v"(accP[0][0][0]), "v"(accP[0][1][0]), "v"(accP[1][0][0]), "v"(accP[1][1][0]));
-#elif defined(MVDB_SCAN_ABLATE)  // fast test kept, candidates never handled
-		if (__ballot(mall >= 0)) asm volatile("s_nop 0");
-#else
 		if (__ballot(mall >= 0)) slow_path(accP, mg, gP, pnode0, pvn0, pvn1);
-#endif
 		pvn0 = vn0;
 		pvn1 = vn1;
 		pnode0 = n_begin + tile * kScanStage + half * kScanTN;
-#ifdef MVDB_SCAN_DEBUG
-		dbg_c[0]++;
-#endif
 	};
 	int cur = 0;
 	for (int tile = 0; tile < ntiles; tile++) {
 		const int nxt = cur + 1 == NB ? 0 : cur + 1;
-		const int fill = cur == 0 ? NB - 1 : cur - 1;  // (cur + D) % NB: the buffer of tile + D
 		const bool more = tile + 1 < ntiles;
 		if ((tile % kScanPoll) == 0 && owner && my_qrow < a.nq)
 			ext_next = __hip_atomic_load(&a.thr_g[my_qrow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		pass(tile, cur, 0, cur, 1, tile + D < ntiles, tile + D + 1 < ntiles, fill, accA, gA, accB, gB);
-		pass(tile, cur, 1, (!MVDB_SCAN_DMA && NB >= 3 && more) ? nxt : -1, 0, false, false, fill, accB, gB, accA, gA);
+		pass(tile, cur, 0, cur, 1, accA, gA, accB, gB);
+		pass(tile, cur, 1, -1, 0, accB, gB, accA, gA);
 		if ((tile % kScanPoll) == 1 && __ballot(owner && ext_next < ext)) {  // a tighter bound from another split
 			if (owner && ext_next < ext) {
 				ext = ext_next;
@@ -629,53 +488,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 			}
 			refresh_bounds();
 		}
-#ifdef MVDB_SCAN_DEBUG
-		const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-#endif
-#if MVDB_SCAN_DMA
 		// tile + 1 must have landed: the waves that fetched it wait for their own operations (they
 		// have nothing newer in flight), the barrier covers the rest; tile + 2 (three buffers), fetched
 		// by the other group, stays in flight across the barrier; then the buffer of the tile just
 		// finished takes tile + NB
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef MVDB_SCAN_DEBUG
-		const unsigned long long t_1 = __builtin_amdgcn_s_memtime();
-		dbg_c[8] += t_1 - t_b;  // LDS reads drained
-#endif
-#if MVDB_SCAN_DMA_SPREAD
-		if (NB >= 3 && tile + 2 < ntiles)
-			scan_wait_vm_upto(my_dma);  // tile + 2, issued during this tile, stays in flight
-		else
-			scan_wait_vm<0>();
-#else
 		if (((tile + 1) & 1) == dma_grp) scan_wait_vm<0>();
-#endif
-#ifdef MVDB_SCAN_DEBUG
-		const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
-		dbg_c[9] += t_2 - t_1;  // own DMA landed
-#endif
-#if !(defined(MVDB_SCAN_ABLATE) && (MVDB_SCAN_ABLATE & 32))  // timing experiment (racy, wrong results): waves never wait for each other
 		__builtin_amdgcn_s_barrier();
-#endif
 		asm volatile("" ::: "memory");
-#ifdef MVDB_SCAN_DEBUG
-		const unsigned long long t_3 = __builtin_amdgcn_s_memtime();
-		dbg_c[10] += t_3 - t_2;  // barrier
-#endif
 		if (more) prefetch(nxt, 0);
-#if !MVDB_SCAN_DMA_SPREAD
 		if (tile + NB < ntiles && ((tile + NB) & 1) == dma_grp) dma_issue(tile + NB, cur);
-#endif
-#ifdef MVDB_SCAN_DEBUG
-		dbg_c[11] += __builtin_amdgcn_s_memtime() - t_3;  // prefetch + DMA issue
-#endif
-#else
-		__syncthreads();
-		if (NB < 3 && more) prefetch(nxt, 0);
-#endif
-#ifdef MVDB_SCAN_DEBUG
-		dbg_c[5] += __builtin_amdgcn_s_memtime() - t_b;
-#endif
 		cur = nxt;
 	}
 	if (ntiles > 0) {  // the last pass always ran into accB
@@ -686,11 +508,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(ScanArgs a)
 		if (__ballot((m01 > m23 ? m01 : m23) >= 0)) slow_path(accB, mg, gB, pnode0, pvn0, pvn1);
 	}
 	compact_rows((unsigned)__ballot(owner && cnt[lane & (kScanWR - 1)] > 0));  // every row: best min(n, k), sorted
-#ifdef MVDB_SCAN_DEBUG
-	dbg_c[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
-	if (lane == 0 && a.dbg && !a.wide)  // (a sweep that uses the wide kernel reports that kernel's counters)
-		for (int i = 0; i < 16; i++) atomicAdd(&a.dbg[i], dbg_c[i]);
-#endif
 
 	// ---- per-(query, split) partial lists, sorted ascending
 	if (owner && my_qrow < a.nq) {

@@ -15,9 +15,6 @@
 #include <climits>
 #include <type_traits>
 
-#ifndef MVDB_WIDE_ABLATE
-#define MVDB_WIDE_ABLATE 0  // experiments (timing only, wrong results): 1 no candidate path, 2 no candidate test, 8 no tile fill after the first
-#endif
 
 namespace mvdb {
 
@@ -273,12 +270,7 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 	// slot.  Kept SMALL: it is inlined at every pass site, and with one wave per SIMD an instruction-cache miss is
 	// paid in full -- so a 16 x 16 tile that holds a candidate goes through LDS and one runtime loop handles its
 	// four elements per lane, instead of 32 unrolled copies of the append.
-#ifdef MVDB_SCAN_DEBUG
-	unsigned long long dc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define WIDE_DBG(x) x
-#else
 #define WIDE_DBG(x)
-#endif
 	bool compacted = false;
 	auto slow_path = [&](v4i (&acc)[kWideGR][2], int grp, int node0, int vn0, int vn1, int pgen) {
 		WIDE_DBG(const unsigned long long s_a = __builtin_amdgcn_s_memtime();)
@@ -398,9 +390,7 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 			} else if (next_half >= 0) {
 				load_first(tile, cur, next_half);
 			}
-#if !(MVDB_WIDE_ABLATE & 8)
 			if (dma) tabv = dma_tab_read(i0 + ks);
-#endif
 			__builtin_amdgcn_sched_barrier(0);
 			const int T0 = ks * (kWideGR * 2) / KS, T1 = (ks + 1) * (kWideGR * 2) / KS;  // accY tiles tested in this step (all static once unrolled)
 			const int NP = (T1 - T0) + 1;                                            // pieces: one per tile + the DMA instruction
@@ -415,17 +405,13 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 				for (int p = 0; p < kWideGR * 2 + 1; p++) {
 					if (p >= NP || p * (kWideGR * 2) / NP != m) continue;
 					if (p == NP - 1) {
-#if !(MVDB_WIDE_ABLATE & 8)
 						if (dma) dma_issue_one(i0 + ks, ftile, fill, tabv);
-#endif
 					} else {
-#if !(MVDB_WIDE_ABLATE & 2)
 						const int t = T0 + p;
 						const v4i &v = accY[t >> 1][t & 1];
 						int &mm = my[t & 1];
 						mm = scan_max3(mm, v[0], v[1]);
 						mm = scan_max3(mm, v[2], v[3]);
-#endif
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
@@ -445,11 +431,7 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 	bool p_have = false;
 	int p_grp = 0, p_node0 = 0, p_vn0 = -1, p_vn1 = -1, p_gen = 0;
 	auto handle = [&](v4i (&accY)[kWideGR][2], int mall) {
-#if MVDB_WIDE_ABLATE & 1
-		if (p_have && __ballot(mall >= 0) && a.nq < 0) slow_path(accY, p_grp, p_node0, p_vn0, p_vn1, p_gen);
-#else
 		if (p_have && __ballot(mall >= 0)) slow_path(accY, p_grp, p_node0, p_vn0, p_vn1, p_gen);
-#endif
 		if (compacted || stale) refresh_bounds();  // the one refresh slot per pass
 		compacted = false;
 	};
@@ -512,11 +494,6 @@ __global__ __launch_bounds__(256) void scan_wide_kernel(ScanArgs a)
 		asm volatile("" ::: "memory");
 		WIDE_DBG(dc[5] += __builtin_amdgcn_s_memtime() - d_e;)
 	}
-#ifdef MVDB_SCAN_DEBUG
-	dc[6] = __builtin_amdgcn_s_memtime() - d_t0;
-	if (lane == 0 && a.dbg)
-		for (int i = 0; i < 16; i++) atomicAdd(&a.dbg[i], dc[i]);
-#endif
 	wide_mfma_settle();
 	if (p_have) {  // the last pass (in accQ)
 		handle(accQ, 0);  // (slow_path looks for the candidates itself)

@@ -52,52 +52,50 @@ typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
 typedef __attribute__((address_space(3))) u32x2_t lds_u32x2;
 
 // ---- visited set of one query (hnsw.ts:118-132, :494-495) -------------------------------------
-// Default (MVDB_VISITED_STAMPS=0): a private bitmap per query in global memory, test-and-set by ONE returning
-// atomicOr per listed neighbour, issued together with its row; zeroed by the launcher per batch.  On gfx950 these
-// atomics execute at the memory side (TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r2/pmc_traffic_1m_balanced.json): they
-// are ~27 % of the kernel's HBM-side requests on top of the algorithmic bytes.
-// MVDB_VISITED_STAMPS=1 is the reference's own scheme (a stamp per node, bumped per search) with one BYTE per node:
-// visited iff the byte equals the launch's epoch, so nothing is cleared between launches (the launcher zeroes the
-// slice when the epoch wraps after 255 launches); test = one L1-bypassing byte load, set = one plain store
-// (distinct ids, distinct bytes: no atomics).  Bit-exact like the bitmap (the whole GPU suite passes), but SLOWER
-// on MI355X at 1M x 384, ef 1200: 3.03 vs 2.67 ms per 1k-query launch alone, 375 k vs 405 k queries/s with three
-// batches in flight -- two scattered one-byte requests per neighbour cost more than one atomic.  Kept for A/B runs.
-#ifndef MVDB_VISITED_STAMPS
-#define MVDB_VISITED_STAMPS 0
+// A private bitmap per query in global memory, zeroed by the launcher per batch.  traverse_kernel / traverse_duo_kernel:
+// test-and-set by ONE returning atomicOr per listed neighbour, issued together with its row.  On gfx950 these
+// atomics execute at the memory side (TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r2/pmc_traffic_1m_balanced.json).
+// (The reference's own scheme -- a stamp per node, bumped per search -- was measured as one byte per node with an
+// epoch per launch: bit-exact but slower, 3.03 vs 2.67 ms per 1k-query launch at 1M x 384; see DESIGN.md.)
+#ifndef MVDB_EXP_VIS
+#define MVDB_EXP_VIS 0
 #endif
 struct VisitedSet {
-#if MVDB_VISITED_STAMPS
-	uint8_t *p;
-	unsigned epoch;
-	__device__ __forceinline__ unsigned probe(int id) const
-	{
-		return __hip_atomic_load(p + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-	__device__ __forceinline__ bool seen(unsigned probed, int) const { return probed == epoch; }
-	__device__ __forceinline__ void set(int id) const { p[id] = (uint8_t)epoch; }
-#else
 	uint32_t *p;
-	unsigned epoch;
 	__device__ __forceinline__ unsigned probe(int id) const { return atomicOr(&p[(unsigned)id >> 5], 1u << (id & 31)); }
 	__device__ __forceinline__ bool seen(unsigned probed, int id) const { return (probed >> (id & 31)) & 1u; }
 	__device__ __forceinline__ void set(int) const {}
+	// traverse_lean_kernel: test = a load of the word past the vector L1, set = an atomicOr that returns nothing --
+	// the atomic (executed at the memory side, up to ~3000 cycles under load) is off the query's critical chain.
+	// The caller makes sure its earlier atomics have completed (s_waitcnt vmcnt(0)) before it loads again.
+	__device__ __forceinline__ unsigned load_word(int id) const
+	{
+#if MVDB_EXP_VIS == 2
+		return __hip_atomic_load(&p[(unsigned)id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+		return __hip_atomic_load(&p[(unsigned)id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+	}
+	__device__ __forceinline__ void set_after(int id, unsigned old) const
+	{
+#if MVDB_EXP_VIS
+		__hip_atomic_store(&p[(unsigned)id >> 5], old | (1u << (id & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+		or_noret(id);
+#endif
+	}
+	__device__ __forceinline__ void or_noret(int id) const
+	{
+		(void)__hip_atomic_fetch_or(&p[(unsigned)id >> 5], 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 	__device__ __forceinline__ void mark(int id) const  // the entry point (:452)
 	{
-#if MVDB_VISITED_STAMPS
-		p[id] = (uint8_t)epoch;
-#else
 		atomicOr(&p[(unsigned)id >> 5], 1u << (id & 31));
-#endif
 	}
 };
 __host__ __device__ inline size_t visited_stride_bytes(int max_elements)
 {
-#if MVDB_VISITED_STAMPS
-	return ((size_t)max_elements + 255) & ~(size_t)255;
-#else
 	return (((size_t)max_elements + 31) / 32 * 4 + 255) & ~(size_t)255;
-#endif
 }
 
 // Clean-up by log instead of a memset per batch (mvdb_set_visited_mode(h, 2, cap); NOT the default).  The
@@ -438,7 +436,6 @@ struct TraverseArgs {
 	uint32_t *vis_log;    // nq x vis_log_cap marked ids (VisitedLog) or null: the host clears the bitmaps per launch
 	int vis_log_cap;
 	size_t vis_stride;    // bytes per query
-	unsigned epoch;       // stamp of this launch (1..255) when MVDB_VISITED_STAMPS
 	int32_t *out_ids;     // nq x k
 	float *out_dist;      // nq x k
 	int32_t *out_count;   // nq
@@ -590,9 +587,9 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 
 	MVDB_STAMP(0);  // query load + descent
 	// search_layer(query, cur, 0, ef, false): hnsw.ts:423-523
-	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride), a.epoch};
+	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride)};
 	VisitedLog vlog;
-	vlog.init(MVDB_VISITED_STAMPS ? nullptr : a.vis_log, a.vis_log_cap, qi);
+	vlog.init(a.vis_log, a.vis_log_cap, qi);
 	int cand_size = 0, res_size = 0;
 	{
 		// dist0 (:450) re-evaluates the row the descent ended on: same value, counted, not re-read
@@ -737,9 +734,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 			a.ctr[qi] = c;
 		}
 	}
-#if !MVDB_VISITED_STAMPS
 	vlog.clear(vis.p, a.vis_stride, false, lane);
-#endif
 }
 
 }  // namespace mvdb

@@ -262,9 +262,9 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 
 		MVDB_DUO_STAMP(0);
 		// search_layer(query, cur, 0, ef, false): :450-454
-		const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride), a.epoch};
+		const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride)};
 		VisitedLog vlog;
-		vlog.init(MVDB_VISITED_STAMPS ? nullptr : a.vis_log, a.vis_log_cap, qi);
+		vlog.init(a.vis_log, a.vis_log_cap, qi);
 		int cand_size = 0;
 		n_dist++;  // dist0 (:450) re-evaluates the row the descent ended on
 		if (lane == 0) vis.mark(cur);
@@ -604,10 +604,8 @@ __global__ __launch_bounds__(64 * WAVES) void traverse_duo_kernel(TraverseArgs a
 		if (!published) duo_publish(&sy->record[e & 1], u32x4_t{(unsigned)(e + 1), (unsigned)kRecEnd, 0u, 0u}, lane);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		if (lane == 0) *reinterpret_cast<volatile int *>(&sy->fin) = 1;
-#if !MVDB_VISITED_STAMPS
 		// this wave owns the visited set: leave it zero (behind the other waves' output, which `fin` released)
 		vlog.clear(vis.p, a.vis_stride, dead, lane);
-#endif
 		return;
 	}
 

@@ -55,8 +55,10 @@ enum : int {
 
 // LLVM's uniformity analysis marks EVERY phi of a join block divergent when a lane-dependent branch joins there,
 // also the ones that merge wave-uniform control flow ending in the same block -- and one such phi in the
-// expansion loop turns all of its scalar state into vector registers under EXEC masks.  An empty volatile asm
-// behind a lane-dependent `if` keeps its join block apart from the enclosing uniform one.
+// expansion loop turns all of its scalar state into vector registers under EXEC masks.  So this kernel has (almost)
+// no lane-dependent branch: a masked-off lane stores to a dummy address instead (entry 0 of a heap array, or its own
+// dword of a dump area), loads a valid address and discards the value.  Where a branch remains (global atomics),
+// an empty volatile asm behind it keeps its join block apart from the enclosing uniform one.
 #define MVDB_LANE_JOIN() asm volatile("")
 
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
@@ -66,6 +68,21 @@ __device__ __forceinline__ void lds_w16(unsigned a, unsigned v) { *reinterpret_c
 __device__ __forceinline__ unsigned lds_r32(unsigned a) { return *reinterpret_cast<const lds_u32 *>((size_t)a); }
 __device__ __forceinline__ void lds_w32(unsigned a, unsigned v) { *reinterpret_cast<lds_u32 *>((size_t)a) = v; }
 
+// key (u16) and id (u32) of one heap slot in ONE LDS round trip (hipcc otherwise issues the second read only after
+// it has waited for the first)
+__device__ __forceinline__ void lds_r16_r32(unsigned a16, unsigned a32, unsigned &k, unsigned &i)
+{
+	asm volatile("ds_read_u16 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(k), "=&v"(i) : "v"(a16), "v"(a32) : "memory");
+}
+// two slots (root and last entry of a pop) in one round trip
+__device__ __forceinline__ void lds_r16_r32_x2(unsigned a16, unsigned a32, unsigned b16, unsigned b32, unsigned &ka, unsigned &ia,
+                                               unsigned &kb_, unsigned &ib_)
+{
+	asm volatile("ds_read_u16 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_u16 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+	             : "=&v"(ka), "=&v"(ia), "=&v"(kb_), "=&v"(ib_)
+	             : "v"(a16), "v"(a32), "v"(b16), "v"(b32)
+	             : "memory");
+}
 __device__ __forceinline__ unsigned lean_readlane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ unsigned long long lean_lt_mask(int lane) { return (1ull << lane) - 1; }
 // a wave-uniform 64-bit mask the compiler could not prove uniform: pin it to scalar registers (loops over its bits
@@ -104,13 +121,22 @@ __device__ __forceinline__ unsigned lean_wave_sum(unsigned x)
 	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false);
 	return lean_readlane(x, 0) + lean_readlane(x, 16) + lean_readlane(x, 32) + lean_readlane(x, 48);
 }
+// c ? a : b per lane, opaque to the optimiser: LLVM turns a store whose ADDRESS is a select back into a
+// lane-dependent branch around two stores -- the very thing the dummy addresses are there to avoid
+__device__ __forceinline__ unsigned lean_sel(bool c, unsigned a, unsigned b)
+{
+	unsigned r;
+	const unsigned long long m = __ballot(c);
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+	return r;
+}
 // whole-wave shift by one lane (DPP wave_shr:1)
 __device__ __forceinline__ unsigned lean_shr1(unsigned x, unsigned fill)  // lane l <- lane l-1, lane 0 <- fill
 {
 	return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
 }
 
-// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | flat result keys u16[ef+576] | 4 x 64 dwords of buffers
+// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | flat result keys u16[ef+576] | 5 x 64 dwords of buffers
 struct LeanCarve {
 	unsigned ck, ci, lowk, buf;
 	size_t total;
@@ -126,7 +152,7 @@ __host__ __device__ inline LeanCarve lean_carve(int ef, int cand_cap)
 	c.lowk = o;
 	o += ((unsigned)(ef + kLeanLowSlack + 64) * 2u + 15u) & ~15u;
 	c.buf = o;
-	o += 4u * 64u * 4u;
+	o += 5u * 64u * 4u;  // all_ids | all_dist | buf_a | buf_b | one dword per lane where masked-off stores go
 	c.total = o;
 	return c;
 }
@@ -145,10 +171,11 @@ struct LeanCand {
 		const unsigned pos = (unsigned)size + 1u;
 		const unsigned sh = lane < 31 ? (unsigned)lane : 31u;
 		const unsigned self = pos >> sh, anc = self >> 1;
-		const unsigned ek = lds_r16(kb + 2u * anc), ei = lds_r32(ib + 4u * anc);
+		unsigned ek, ei;
+		lds_r16_r32(kb + 2u * anc, ib + 4u * anc, ek, ei);
 		const bool stop = anc == 0u || ek <= nkey;
 		const int Jn = __builtin_ctzll(__ballot(stop));
-		const unsigned dst = lane <= Jn ? self : 0u;
+		const unsigned dst = lean_sel(lane <= Jn, self, 0u);
 		lds_w16(kb + 2u * dst, lane == Jn ? nkey : ek);
 		lds_w32(ib + 4u * dst, lane == Jn ? nid : ei);
 	}
@@ -163,39 +190,34 @@ struct LeanCand {
 		const int li = lane + 2;
 		const int d = 31 - __builtin_clz(li);  // 1..5 (6 in the two spare lanes)
 		const int off = li - (1 << d);
+		// the lanes of this node's ancestors inside the 62-node subtree, itself included: the walk passes through the
+		// node iff every one of them is a chosen child the walk continues through
+		unsigned long long anc = 0;
+		for (int x = li; x >= 2; x >>= 1) anc |= 1ull << (x - 2);
+		anc = lane < 62 ? anc : ~0ull;
 		for (;;) {
 			if (2 * p > size) break;  // a leaf
 			const int pos = (p << d) + off;
 			const bool valid = lane < 62 && pos <= size;
 			const unsigned slot = valid ? (unsigned)pos : 0u;
-			unsigned ek = lds_r16(kb + 2u * slot);
-			const unsigned ei = lds_r32(ib + 4u * slot);
+			unsigned ek, ei;
+			lds_r16_r32(kb + 2u * slot, ib + 4u * slot, ek, ei);
 			ek = valid ? ek : kLeanInf;
 			const unsigned ks = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ek, 0xB1, 0xf, 0xf, false);  // sibling
 			const bool chosen = (lane & 1) ? ek < ks : ek <= ks;
 			const unsigned long long cont = __ballot(chosen && nkey > ek);
-			unsigned long long path = 0;
-			int cur = 1, steps = 0;
-			for (; steps < 5; steps++) {
-				const unsigned pair = (unsigned)(cont >> (2 * cur - 2)) & 3u;  // at most one bit: one child is chosen
-				if (!pair) break;
-				cur = 2 * cur + (int)(pair >> 1);
-				path |= 1ull << (cur - 2);
-			}
-			if ((path >> lane) & 1ull) {
-				lds_w16(kb + 2u * (unsigned)(pos >> 1), ek);
-				lds_w32(ib + 4u * (unsigned)(pos >> 1), ei);
-			}
-			MVDB_LANE_JOIN();
+			const unsigned long long path = __ballot((cont & anc) == anc);  // at most one node per level
+			const unsigned up = lean_sel((path >> lane) & 1ull, (unsigned)(pos >> 1), 0u);  // entry 0 is never read
+			lds_w16(kb + 2u * up, ek);
+			lds_w32(ib + 4u * up, ei);
+			if (path == 0ull) break;  // the walk stops at p
+			const int cur = 65 - __builtin_clzll(path);  // the deepest node on the path (numbering grows with depth)
 			const int dc = 31 - __builtin_clz(cur);
 			p = (p << dc) + (cur - (1 << dc));
-			if (steps < 5) break;
+			if (dc < 5) break;
 		}
-		if (lane == 0) {
-			lds_w16(kb + 2u * (unsigned)p, nkey);
-			lds_w32(ib + 4u * (unsigned)p, nid);
-		}
-		MVDB_LANE_JOIN();
+		lds_w16(kb + 2u * (unsigned)p, nkey);  // every lane, the same value
+		lds_w32(ib + 4u * (unsigned)p, nid);
 	}
 };
 
@@ -228,7 +250,7 @@ struct KeyWin {
 // distances of rows ids_s[0..n) -> dist_s[0..n) as exact integers; `big` collects "above 65535" per lane
 template <int J, bool FULL>
 __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const QueryRegs<J> &Q, const int *ids_s, unsigned *dist_s,
-                                               int n, int safe_row, int lane, bool &big)
+                                               int n, int safe_row, int lane, bool &big, unsigned dump)
 {
 	const int g = lane >> 3, s = lane & 7;
 	for (int p0 = 0; p0 < n; p0 += 32) {
@@ -237,7 +259,8 @@ __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const Que
 #pragma unroll
 		for (int pp = 0; pp < 4; pp++) {
 			slot[pp] = p0 + pp * 8 + g;
-			const int rid = slot[pp] < n ? ids_s[slot[pp]] : safe_row;
+			int rid = ids_s[slot[pp] < n ? slot[pp] : 0];
+			rid = slot[pp] < n ? rid : safe_row;
 			if (p0 + pp * 8 < n) load_row<J, FULL>(v[pp], ix, rid, s);
 		}
 #pragma unroll
@@ -245,8 +268,7 @@ __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const Que
 			if (p0 + pp * 8 < n) {
 				const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v[pp])));
 				big = big || (slot[pp] < n && tot > kLeanKeyMax);
-				if (s == 0 && slot[pp] < n) dist_s[slot[pp]] = tot;
-				MVDB_LANE_JOIN();
+				lds_w32(lean_sel(s == 0 && slot[pp] < n, (unsigned)(size_t)dist_s + 4u * (unsigned)slot[pp], dump), tot);
 			}
 		}
 	}
@@ -256,6 +278,10 @@ __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const Que
 // phase, 2 candidate-heap work in the shadow of the loads, 3 rows + distances, 4 visited test + compaction,
 // 5 admission (6 = the refills inside it), 7 log + prediction; counters: 8 lists not prefetched, 9 admitted
 // neighbours, 10 refills, 11 of them dense, 12 expansions whose next candidate came out of the list itself
+#ifdef MVDB_LEAN_MARK  // instruction-count study: phase boundaries show up in the assembly listing (never shipped)
+#undef MVDB_STAMP
+#define MVDB_STAMP(slot) asm volatile("; LEANMARK " #slot)
+#endif
 #ifdef MVDB_TRAVERSE_PROFILE
 #define MVDB_LEAN_COUNT(slot, v) prof_acc[slot] += (unsigned long long)(v)
 #else
@@ -293,6 +319,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	int *buf_a = reinterpret_cast<int *>(all_dist + 64);      // compacted ids | descent codes | refill histogram
 	unsigned *buf_b = reinterpret_cast<unsigned *>(buf_a + 64);  // compacted distances | refill staging
 	const unsigned hist = lds0 + cv.buf + 512u, stage = lds0 + cv.buf + 768u;
+	const unsigned dump = lds0 + cv.buf + 1024u + 4u * (unsigned)lane;  // where this lane's masked-off LDS stores go
 
 	QueryRegs<J> Q;
 	load_query<J>(Q, a.q + (size_t)qi * (size_t)ix.dim, ix.dim, lane);
@@ -305,9 +332,8 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	int cur = ix.entry, cur_code = ix.entry_code;
 	unsigned cur_d;
 	{
-		if (lane == 0) all_ids[0] = cur;
-		MVDB_LANE_JOIN();
-		lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, 1, cur, lane, big);
+		all_ids[0] = cur;  // every lane, the same value
+		lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, 1, cur, lane, big, dump);
 		cur_d = (unsigned)rfl((int)all_dist[0]);
 		n_dist++;
 	}
@@ -325,12 +351,9 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				if (base + lane >= ix.m) en = make_int2(-1, -1);
 				const int n = __builtin_popcountll(__ballot(en.x >= 0));  // canonical lists: valid entries are a prefix
 				if (n == 0) break;
-				if (en.x >= 0) {
-					all_ids[lane] = en.x;
-					buf_a[lane] = en.y;
-				}
-				MVDB_LANE_JOIN();
-				lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, n, cur, lane, big);
+				all_ids[lane] = en.x;
+				buf_a[lane] = en.y;
+				lean_dist_rows<J, FULL>(ix, Q, all_ids, all_dist, n, cur, lane, big, dump);
 				n_dist += n;
 				// sequential scan with strict `<` == first occurrence of the minimum, if below cur_d
 				const unsigned my = lane < n ? all_dist[lane] : kLeanInf;
@@ -349,8 +372,8 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	MVDB_STAMP(0);
 
 	// ---------------- search_layer(query, cur, 0, ef, false): :423-523 ----------------
-	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride), a.epoch};
-	uint2 *log = a.adm_log + (size_t)qi * (size_t)a.adm_log_cap;
+	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride)};
+	uint2 *log = a.adm_log + (size_t)qi * (size_t)(a.adm_log_cap + 64);
 	int cand_size = 0, res_size = 0, low_n = 0, n_adm = 0, s_hint = 0;
 	unsigned worst = kLeanInf;  // max of the result keys; consulted only once res_size >= ef
 	const int low_cap = ef + kLeanLowSlack;
@@ -362,11 +385,10 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		for (int i0 = 0; i0 < low_n; i0 += 64) {
 			const int i = i0 + lane;
 			const bool valid = i < low_n;
-			const unsigned k = valid ? lds_r16(lowk + 2u * (unsigned)i) : 0u;
+			const unsigned k = lds_r16(lowk + 2u * (unsigned)(valid ? i : 0));
 			const bool keep = valid && k < win.T;
 			const unsigned long long km = __ballot(keep);
-			if (keep) lds_w16(lowk + 2u * (unsigned)(newn + __builtin_popcountll(km & lean_lt_mask(lane))), k);
-			MVDB_LANE_JOIN();
+			lds_w16(lean_sel(keep, lowk + 2u * (unsigned)(newn + __builtin_popcountll(km & lean_lt_mask(lane))), dump), k);
 			newn += __builtin_popcountll(km);
 		}
 		low_n = newn;
@@ -375,13 +397,12 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	auto low_append = [&](unsigned long long mask, unsigned my_d) __attribute__((always_inline)) {
 		const int n = __builtin_popcountll(mask);
 		if (low_n + n > low_cap) low_compact();  // <= ef alive entries remain
-		if ((mask >> lane) & 1ull) lds_w16(lowk + 2u * (unsigned)(low_n + __builtin_popcountll(mask & lean_lt_mask(lane))), my_d);
-		MVDB_LANE_JOIN();
+		lds_w16(lean_sel((mask >> lane) & 1ull, lowk + 2u * (unsigned)(low_n + __builtin_popcountll(mask & lean_lt_mask(lane))), dump), my_d);
 		low_n += n;
 	};
 	// 8 keys of the flat array per lane and step
 	auto low_vec = [&](int vi, int nvec) __attribute__((always_inline)) -> uint4 {
-		return vi < nvec ? lds_read16(reinterpret_cast<const void *>((size_t)(lowk + 16u * (unsigned)vi))) : make_uint4(0u, 0u, 0u, 0u);
+		return lds_read16(reinterpret_cast<const void *>((size_t)(lowk + 16u * (unsigned)(vi < nvec ? vi : 0))));  // callers mask by index
 	};
 	auto low_key = [](const uint4 &kv, int e) __attribute__((always_inline)) -> unsigned {
 		const unsigned w = e < 2 ? kv.x : (e < 4 ? kv.y : (e < 6 ? kv.z : kv.w));
@@ -407,10 +428,9 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				for (int e = 0; e < 8; e++) {
 					const unsigned k = low_key(kv, e);
 					const unsigned b = (T - 1u - k) >> s;  // k >= T wraps far beyond 64 bins
-					if (vi < nvec && 8 * vi + e < low_n && k < T && b < 64u)
-						__hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)(hist + 4u * b)), 1u, __ATOMIC_RELAXED,
-						                       __HIP_MEMORY_SCOPE_WORKGROUP);
-					MVDB_LANE_JOIN();
+					const bool in = vi < nvec && 8 * vi + e < low_n && k < T && b < 64u;
+					__hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)lean_sel(in, hist + 4u * b, dump)), lean_sel(in, 1u, 0u), __ATOMIC_RELAXED,
+					                       __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 			}
 			const unsigned long long nz0 = __ballot(lds_r32(hist + 4u * (unsigned)lane) != 0u);
@@ -427,7 +447,8 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			const int f = __builtin_ctzll(nz0);
 			T -= (unsigned)f << s;  // no alive key in [T - (f << s), T): the floor drops to the first occupied bin
 			limit = 64 - f;
-			hc = lane < limit ? lds_r32(hist + 4u * (unsigned)(lane + f)) : 0u;
+			hc = lds_r32(hist + 4u * (unsigned)(lane < limit ? lane + f : 0));
+			hc = lane < limit ? hc : 0u;
 			if (s == 0) {
 				Tn = T >= (unsigned)limit ? T - (unsigned)limit : 0u;
 				break;
@@ -450,8 +471,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		if (dense) {
 			const unsigned long long nz = __ballot(hc != 0u);
 			const unsigned long long above = lane == 63 ? 0ull : (nz >> (lane + 1));  // occupied bins of smaller key values
-			if (hc != 0u) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(above), ((T - 1u - (unsigned)lane) & 0xffffu) | (hc << 16));
-			MVDB_LANE_JOIN();
+			lds_w32(lean_sel(hc != 0u, stage + 4u * (unsigned)__builtin_popcountll(above), dump), ((T - 1u - (unsigned)lane) & 0xffffu) | (hc << 16));
 			const unsigned v = lds_r32(stage + 4u * (unsigned)lane);
 			win.wk = v & 0xffffu;
 			win.wc = v >> 16;
@@ -460,39 +480,37 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			s_hint = win.total >= 24 ? 0 : (win.total >= 12 ? 1 : (win.total >= 6 ? 2 : 3));
 		} else {
 			// collect the keys in [Tn, T): acc <= kLeanTake of them, in any order
-			lds_w32(hist, 0u);
+			int cpos = 0;
 			for (int v0 = 0; v0 < nvec; v0 += 64) {
 				const int vi = v0 + lane;
 				const uint4 kv = low_vec(vi, nvec);
 #pragma unroll
 				for (int e = 0; e < 8; e++) {
 					const unsigned k = low_key(kv, e);
-					if (vi < nvec && 8 * vi + e < low_n && k < T && k >= Tn) {
-						const unsigned pos = __hip_atomic_fetch_add(reinterpret_cast<lds_u32 *>((size_t)hist), 1u, __ATOMIC_RELAXED,
-						                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-						lds_w32(stage + 4u * pos, k);
-					}
-					MVDB_LANE_JOIN();
+					const bool in = vi < nvec && 8 * vi + e < low_n && k < T && k >= Tn;
+					const unsigned long long tm = __ballot(in);
+					lds_w32(lean_sel(in, stage + 4u * (unsigned)(cpos + __builtin_popcountll(tm & lean_lt_mask(lane))), dump), k);
+					cpos += __builtin_popcountll(tm);
 				}
 			}
 			const int cnt = acc;
-			const unsigned key = lane < cnt ? lds_r32(stage + 4u * (unsigned)lane) : kLeanInf;
+			unsigned key = lds_r32(stage + 4u * (unsigned)lane);
+			key = lane < cnt ? key : kLeanInf;
 			unsigned lt = 0, eqb = 0;  // rank by counting
 			for (int j = 0; j < cnt; j++) {
 				const unsigned kj = lean_readlane(key, j);
 				lt += kj < key ? 1u : 0u;
 				eqb += (kj == key && j < lane) ? 1u : 0u;
 			}
-			if (lane < cnt) lds_w32(hist + 4u * (lt + eqb), key);
-			MVDB_LANE_JOIN();
-			const unsigned sk = lane < cnt ? lds_r32(hist + 4u * (unsigned)lane) : kLeanInf;
+			lds_w32(lean_sel(lane < cnt, hist + 4u * (lt + eqb), dump), key);
+			unsigned sk = lds_r32(hist + 4u * (unsigned)lane);
+			sk = lane < cnt ? sk : kLeanInf;
 			const unsigned prev = lean_shr1(sk, kLeanInf);
 			const bool head = lane < cnt && (lane == 0 || sk != prev);
 			const unsigned long long hm = __ballot(head);
 			const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
 			const int next = above ? lane + 1 + __builtin_ctzll(above) : cnt;
-			if (head) lds_w32(stage + 4u * (unsigned)__builtin_popcountll(hm & lean_lt_mask(lane)), sk | ((unsigned)(next - lane) << 16));
-			MVDB_LANE_JOIN();
+			lds_w32(lean_sel(head, stage + 4u * (unsigned)__builtin_popcountll(hm & lean_lt_mask(lane)), dump), sk | ((unsigned)(next - lane) << 16));
 			const unsigned v = lds_r32(stage + 4u * (unsigned)lane);
 			win.wk = v & 0xffffu;
 			win.wc = v >> 16;
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	unsigned o_key = 0;
 	bool first = true;  // the entry point goes through the loop once as a list of one new neighbour, without a memory phase
 	if (bail < 0) {
-		if (lane == 0) vis.mark(cur);  // :452
+		if (lane == 0) vis.or_noret(cur);  // :452
 		MVDB_LANE_JOIN();
 		touched = true;
 	}
@@ -609,18 +627,18 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			// listed neighbours were new, the rows of EVERY listed neighbour with it (one round trip instead of two)
 			const bool spec = cnt > 0 && 2 * seen_new >= seen_listed;
 			const int g = lane >> 3, sl = lane & 7;
-			unsigned old = 0;
 			int4 v0[4][J];  // 32 rows per pass, all in flight at once
 			int slot0[4];
-			if (cnt > 0 && nb >= 0) old = vis.probe(nb);
-			MVDB_LANE_JOIN();
+			// the bits this query set so far must have landed before its visited words are read again
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			const unsigned old = vis.load_word(nb >= 0 ? nb : 0);  // (every lane loads; masked below)
 			if (spec) {
-				if (nb >= 0) all_ids[lane] = nb;
-				MVDB_LANE_JOIN();
+				all_ids[lane] = nb;
 #pragma unroll
 				for (int pp = 0; pp < 4; pp++) {
 					slot0[pp] = pp * 8 + g;
-					const int rid = slot0[pp] < cnt ? all_ids[slot0[pp]] : c_id;
+					int rid = all_ids[slot0[pp] < cnt ? slot0[pp] : 0];
+					rid = slot0[pp] < cnt ? rid : c_id;
 					if (pp * 8 < cnt) load_row<J, FULL>(v0[pp], ix, rid, sl);
 				}
 			}
@@ -632,21 +650,29 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				cand.push(cand_size++, (unsigned)__builtin_amdgcn_readlane(p_id, t), lean_readlane(p_d, t), lane);
 			}
 			pend = 0;
+			unsigned lk, li;
 			{
-				const unsigned rk = (unsigned)rfl((int)cand.key_at(1));
-				const int ri = rfl((int)cand.id_at(1));
-				if (cand_size <= 0 || ri != c_id || rk != c_d) {
+				unsigned rk, ri;  // root and last entry in one round trip
+				const unsigned last = (unsigned)(cand_size > 0 ? cand_size : 1);
+				lds_r16_r32_x2(cand.kb + 2u, cand.ib + 4u, cand.kb + 2u * last, cand.ib + 4u * last, rk, ri, lk, li);
+				rk = (unsigned)rfl((int)rk);
+				ri = (unsigned)rfl((int)ri);
+				lk = (unsigned)rfl((int)lk);
+				li = (unsigned)rfl((int)li);
+				if (cand_size <= 0 || (int)ri != c_id || rk != c_d) {
 					bail = kLeanMismatch;
 					break;
 				}
 			}
 			cand_size--;
 			if (cand_size > 0) {
-				const unsigned lk = (unsigned)rfl((int)cand.key_at(cand_size + 1));
-				const unsigned li = (unsigned)rfl((int)cand.id_at(cand_size + 1));
 				cand.sift_root(cand_size, li, lk, lane);
-				o_key = (unsigned)rfl((int)cand.key_at(1));
-				o_id = rfl((int)cand.id_at(1));
+				{
+					unsigned ok_, oi_;
+					lds_r16_r32(cand.kb + 2u, cand.ib + 4u, ok_, oi_);
+					o_key = (unsigned)rfl((int)ok_);
+					o_id = rfl((int)oi_);
+				}
 				if (pref_id != o_id) {  // needed next unless a new neighbour undercuts it
 					pref_id = o_id;
 					pref_nb = ix.adj0[(size_t)o_id * (size_t)m0 + lane_m0];
@@ -659,8 +685,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				for (int pp = 0; pp < 4; pp++) {
 					if (pp * 8 < cnt) {
 						const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v0[pp])));
-						if (sl == 0 && slot0[pp] < cnt) all_dist[slot0[pp]] = tot;
-						MVDB_LANE_JOIN();
+						lds_w32(lean_sel(sl == 0 && slot0[pp] < cnt, (unsigned)(size_t)all_dist + 4u * (unsigned)slot0[pp], dump), tot);
 					}
 				}
 				if (cnt > 32) {  // lists of up to 64 neighbours: a second pass
@@ -669,15 +694,15 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 #pragma unroll
 					for (int pp = 0; pp < 4; pp++) {
 						slot1[pp] = 32 + pp * 8 + g;
-						const int rid = slot1[pp] < cnt ? all_ids[slot1[pp]] : c_id;
+						int rid = all_ids[slot1[pp] < cnt ? slot1[pp] : 0];
+						rid = slot1[pp] < cnt ? rid : c_id;
 						if (32 + pp * 8 < cnt) load_row<J, FULL>(v1[pp], ix, rid, sl);
 					}
 #pragma unroll
 					for (int pp = 0; pp < 4; pp++) {
 						if (32 + pp * 8 < cnt) {
 							const unsigned tot = (unsigned)(Q.qq + reduce8(row_partial<J>(Q, v1[pp])));
-							if (sl == 0 && slot1[pp] < cnt) all_dist[slot1[pp]] = tot;
-							MVDB_LANE_JOIN();
+							lds_w32(lean_sel(sl == 0 && slot1[pp] < cnt, (unsigned)(size_t)all_dist + 4u * (unsigned)slot1[pp], dump), tot);
 						}
 					}
 				}
@@ -685,16 +710,19 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				const bool isnew = nb >= 0 && !vis.seen(old, nb);
 				const unsigned long long nm = __ballot(isnew);
 				n = __builtin_popcountll(nm);
-				if (isnew) {
+				{
 					const int pos = __builtin_popcountll(nm & lean_lt_mask(lane));
 					const unsigned dd = all_dist[lane];  // :497
-					big = big || dd > kLeanKeyMax;
-					buf_a[pos] = nb;
-					buf_b[pos] = dd;
+					big = big || (isnew && dd > kLeanKeyMax);
+					lds_w32(lean_sel(isnew, (unsigned)(size_t)buf_a + 4u * (unsigned)pos, dump), (unsigned)nb);
+					lds_w32(lean_sel(isnew, (unsigned)(size_t)buf_b + 4u * (unsigned)pos, dump), dd);
 				}
+				if (isnew) vis.set_after(nb, old);  // :495, off the chain: nothing waits for it before the next list's words are read
 				MVDB_LANE_JOIN();
-				my_d = lane < n ? buf_b[lane] : kLeanInf;
-				my_id = lane < n ? buf_a[lane] : -1;
+				my_d = buf_b[lane];
+				my_d = lane < n ? my_d : kLeanInf;
+				my_id = buf_a[lane];
+				my_id = lane < n ? my_id : -1;
 				MVDB_STAMP(4);
 			} else if (cnt > 0) {
 				// rows of the NEW neighbours only, after the visited words are back
@@ -703,11 +731,14 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				n = __builtin_popcountll(nm);
 				MVDB_STAMP(4);
 				if (n > 0) {
-					if (isnew) buf_a[__builtin_popcountll(nm & lean_lt_mask(lane))] = nb;
+					lds_w32(lean_sel(isnew, (unsigned)(size_t)buf_a + 4u * (unsigned)__builtin_popcountll(nm & lean_lt_mask(lane)), dump), (unsigned)nb);
+					lean_dist_rows<J, FULL>(ix, Q, buf_a, buf_b, n, c_id, lane, big, dump);  // :497
+					if (isnew) vis.set_after(nb, old);  // :495
 					MVDB_LANE_JOIN();
-					lean_dist_rows<J, FULL>(ix, Q, buf_a, buf_b, n, c_id, lane, big);  // :497
-					my_d = lane < n ? buf_b[lane] : kLeanInf;
-					my_id = lane < n ? buf_a[lane] : -1;
+					my_d = buf_b[lane];
+					my_d = lane < n ? my_d : kLeanInf;
+					my_id = buf_a[lane];
+					my_id = lane < n ? my_id : -1;
 				}
 				MVDB_STAMP(3);
 			}
@@ -744,8 +775,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			bool need_refill = false;
 			if (res_size < ef) {  // :504-505 while the result set fills up everything is admitted
 				const int f = n < ef - res_size ? n : ef - res_size;
-				if (lane < f) lds_w16(lowk + 2u * (unsigned)(low_n + lane), my_d);
-				MVDB_LANE_JOIN();
+				lds_w16(lean_sel(lane < f, lowk + 2u * (unsigned)(low_n + lane), dump), my_d);
 				low_n += f;
 				res_size += f;
 				adm = f >= 64 ? ~0ull : ((1ull << f) - 1);
@@ -759,7 +789,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 #pragma unroll
 						for (int e = 0; e < 8; e++) {
 							const unsigned k = low_key(kv, e);
-							mx = (vi < nvec && 8 * vi + e < low_n && k > mx) ? k : mx;
+							mx = ((vi < nvec) & (8 * vi + e < low_n) & (k > mx)) ? k : mx;
 						}
 					}
 					win.T = lean_wave_max(mx) + 1u;
@@ -827,8 +857,8 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				bail = kLeanLogFull;
 				break;
 			}
-			if ((adm >> lane) & 1ull) log[n_adm + __builtin_popcountll(adm & lean_lt_mask(lane))] = make_uint2(my_d, (unsigned)my_id);
-			MVDB_LANE_JOIN();
+			// (masked-off lanes write behind the log's capacity: the launcher allocates 64 entries more per query)
+			log[lean_sel((adm >> lane) & 1ull, (unsigned)(n_adm + __builtin_popcountll(adm & lean_lt_mask(lane))), (unsigned)(a.adm_log_cap + lane))] = make_uint2(my_d, (unsigned)my_id);
 			n_adm += na;
 		}
 		MVDB_STAMP(5);
@@ -918,7 +948,7 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 	HeapPipe<false> rpipe;
 	rpipe.base = (unsigned)(size_t)res_h;
 	const int n_adm = rfl(a.adm_n[qi]);
-	const uint2 *log = a.adm_log + (size_t)qi * (size_t)a.adm_log_cap;
+	const uint2 *log = a.adm_log + (size_t)qi * (size_t)(a.adm_log_cap + 64);
 	int res_size = 0;
 	uint2 cur = lane < n_adm ? log[lane] : make_uint2(0u, 0u);
 	for (int c0 = 0; c0 < n_adm; c0 += 64) {

@@ -1,7 +1,9 @@
-"""BASELINE.json's configurations at (or, for the sharded ones, at one shard's proxy of) their real sizes, through the
+"""BASELINE.json's configurations at their real sizes (for the sharded ones: one shard at its real size), through the
 C ABI: size-independent properties of the whole pipeline plus oracle equality on a sample of the same queries.
 The graphs come from the engine's GPU builder (a sequential reference build of 1 M nodes takes hours), the oracle
 loads the very dump the engine searched."""
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import pytest
 
@@ -16,12 +18,19 @@ def _build(n, dim, preset, seed=12345):
     b = HipBridge()
     b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], efSearch=p["baseEfSearch"], capacity=n, seed=42,
                 resultsCap=4096))
-    rng = np.random.default_rng(seed)
     base = np.empty((n, dim), np.float32)
     b8 = np.empty((n, dim), np.int8)
-    for s in range(0, n, 131072):
-        e = min(n, s + 131072)
-        base[s:e], b8[s:e] = b.prepareQueries(rng.standard_normal((e - s, dim), dtype=np.float32))
+    chunk = 131072
+
+    def draw(ci):                                                  # one generator per chunk: a few host threads draw
+        s0 = ci * chunk
+        np.random.default_rng([seed, ci]).standard_normal((min(chunk, n - s0), dim), dtype=np.float32,
+                                                          out=base[s0:s0 + chunk])
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(draw, range(-(-n // chunk))))
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        base[s:e], b8[s:e] = b.prepareQueries(base[s:e])
     stats = b.buildGpu(b8)
     return b, p, base, b8, stats
 
@@ -66,18 +75,20 @@ def test_config2_one_million_balanced(gpu):
     b.close()
 
 
-def test_config4_shard_proxy_accurate(gpu):
-    """configs[3]'s preset on one shard-sized piece scaled to test time: accurate (M 32, M_MAX0 64, ef_construction 800,
-    ef = annK = 2500, candidate heap at the 4096 cap)."""
-    n, dim, nq = 150_000, 384, 256
+def test_config4_shard_accurate(gpu):
+    """configs[3]: one of the 8 shards of 10 M x 384 at its real size, 1.25 M nodes, preset accurate (M 24, M_MAX0 48,
+    ef_construction 600, ef = annK = 2500: the candidate heap runs at its 4096-entry cap and drops pushes silently,
+    hnsw.ts:500)."""
+    n, dim, nq = 1_250_000, 384, 256
     b, p, base, b8, stats = _build(n, dim, "accurate", seed=777)
+    assert (p["m"], p["ef_construction"]) == (24, 600)
     tk, ef, ann_k = derive_search_params(10, p)
     assert (ef, ann_k) == (200, 2500)
     q = np.random.default_rng(4321).standard_normal((nq, dim), dtype=np.float32)
     qn, q8 = b.prepareQueries(q)
     b.attachF32(base, resident=True)
     ti, tl, tn = b.queryMany(q, tk, ef, ann_k)
-    assert np.all(tn == tk)
+    assert np.all(tn == tk) and np.all(np.diff(tl, axis=1) >= 0)
     ix = _oracle_of(b, dim, p)
     sub = slice(0, 16)
     oi, ol, on, ann, acnt, _ = O.search_many_db(ix, q[sub], base, 10, "accurate", threads=8)
@@ -85,25 +96,28 @@ def test_config4_shard_proxy_accurate(gpu):
     b.setEfSearch(ef)
     ids, dist, cnt = b.searchManyArrays(q8[sub], ann_k)
     assert np.array_equal(ids, ann) and np.array_equal(cnt, acnt)
+    assert b.leanFallbacks() == dict(big_key=0, log_full=0, mismatch=0)
     ix.close()
     b.close()
 
 
-def test_north_star_scale_beyond_2gib_of_rows(gpu):
-    """Towards the north-star target (10 M x 384 on one GPU; bench.py --rows 10000000 runs it in full): 6 M nodes put
-    the int8 rows past 2 GiB and the float32 store past 8 GiB, so every row offset needs 64-bit arithmetic, and the
-    visited sets of one 500-query batch take 375 MB.  Oracle equality on a sample, properties on the rest."""
-    n, dim, nq = 6_000_000, 384, 500
+def test_config5_shard_balanced_host_f32(gpu):
+    """configs[4]: one of the 8 shards of 100 M x 384 at its real size, 12.5 M nodes, preset balanced, float32 store
+    in pinned host memory (preloadVectors = false: the rerank reads its rows over PCIe).  The int8 rows (4.8 GB) and
+    the float32 store (19.2 GB) are far past 2 GiB, so every row offset needs 64-bit arithmetic; the visited sets of one
+    256-query batch take 400 MB.  Oracle equality on 8 queries, properties on the rest; the same answers with the
+    store in HBM."""
+    n, dim, nq = 12_500_000, 384, 256
     b, p, base, b8, stats = _build(n, dim, "balanced", seed=99)
     tk, ef, ann_k = derive_search_params(10, p)
     q = np.random.default_rng(11).standard_normal((nq, dim), dtype=np.float32)
     q[7] = base[n - 1] * 3.0                                      # a stored vector from the far end of the store
     qn, q8 = b.prepareQueries(q)
-    b.attachF32(base, resident=True)
+    b.attachF32(base, resident=False)
     ti, tl, tn = b.queryMany(q, tk, ef, ann_k)
     assert np.all(tn == tk) and np.all(np.diff(tl, axis=1) >= 0)
     assert ti[7, 0] == n - 1 and tl[7, 0] < 1e-9
-    assert ti.max() > (1 << 31) // dim                            # answers come from beyond the 2 GiB mark too
+    assert ti.max() > (1 << 32) // dim                            # answers come from beyond the 4 GiB mark too
     t2 = b.queryMany(q, tk, ef, ann_k)
     assert np.array_equal(t2[0], ti) and np.array_equal(t2[1].view(np.uint64), tl.view(np.uint64))
     ix = _oracle_of(b, dim, p)
@@ -111,4 +125,7 @@ def test_north_star_scale_beyond_2gib_of_rows(gpu):
     oi, ol, on, ann, acnt, _ = O.search_many_db(ix, q[sub], base, 10, "balanced", threads=8)
     assert np.array_equal(oi, ti[sub]) and np.array_equal(ol.view(np.uint64), tl[sub].view(np.uint64))
     ix.close()
+    b.attachF32(base, resident=True)                              # the same rows from HBM
+    t3 = b.queryMany(q[:64], tk, ef, ann_k)
+    assert np.array_equal(t3[0], ti[:64]) and np.array_equal(t3[1].view(np.uint64), tl[:64].view(np.uint64))
     b.close()

@@ -1,7 +1,7 @@
 """Workload for the rocprofv3 --pmc passes (HBM traffic of the traversal kernel).
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_run.py
-  (tools/pmc_passes.sh runs every pass; tools/pmc_parse2.py turns them into profiles/rN/pmc_traffic_*.json)
+  (tools/pmc_passes.sh runs every pass; tools/pmc.py traffic turns them into profiles/rN/pmc_traffic_*.json)
 
 Launches, on one 1M x 384 balanced index: (1) a calibration launch of dist_pairs_kernel whose byte
 count is known exactly (it gathers rows with the same 8-lanes-x-16-B pattern as the traversal), then
