@@ -460,8 +460,7 @@ def measure(pl, args, steps, warmup, sustain_s, solo):
     bytes_per_launch = bytes_timed / max(steps, 1)
     achieved = bytes_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
     m0 = 2 * pl.preset["m"]
-    kernel = ("traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else
-              "traverse_duo_kernel" if args.traverse_waves in (2, 3) else "traverse_lean_kernel")
+    kernel = "traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else "traverse_lean_kernel"
     traffic, traffic_source = traffic_record(pl, kernel)
     roofline = dict(bound="hbm", kernel=kernel, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
@@ -585,7 +584,7 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                    roofline=roofline, cpu_baseline=cpu_baseline,
                    counters=dict(mean_n_dist=float(ctr_all[:, 0].mean()), mean_n_l0lists=float(ctr_all[:, 1].mean()),
                                  mean_n_upperlists=float(ctr_all[:, 2].mean())),
-                   lean_fallbacks=bridge.leanFallbacks())
+                   lean_fallbacks=bridge.leanFallbacks(), lean_replays=bridge.leanReplays())
         out.update(extras)
     pl.close()
     del pl, s, bridge
@@ -647,7 +646,7 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                 resident=r3["resident"]["value"], sustained=r3.get("sustained"), recall_at_10=rec3,
                 roofline=r3["roofline"], cpu_baseline=cpu3, build_seconds=round(p3.build_s, 2), build=p3.build_stats,
                 mean_n_dist=float(c3[:, 0].mean()),
-                lean_fallbacks=p3.bridge.leanFallbacks())
+                lean_fallbacks=p3.bridge.leanFallbacks(), lean_replays=p3.bridge.leanReplays())
             p3.close()
             del p3
             torch.cuda.empty_cache()
@@ -793,8 +792,8 @@ def main():
     ap.add_argument("--host-f32", action="store_true", help="float32 store in pinned host memory (preloadVectors=false)")
     ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
-    ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="0 = the engine's default (4 = the lean traversal + result-heap replay); 1-3 = result heap inside the traversal")
+    ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1],
+                    help="0 = the engine's default (lean traversal + result-heap replay); 1 = the one-wave kernel with the result heap inside")
     ap.add_argument("--visited-mode", type=int, default=0, choices=[0, 1, 2],
                     help="visited-bitmap clean-up: 0 / 1 memset per launch (default), 2 the kernel's log-and-clear (measured slower)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",

@@ -246,10 +246,11 @@ int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, i
 
 /* ---- engine state beyond the WASM surface ---------------------------------- */
 /* Kernel variants of the timed path (handle state, read at launch): traverse_waves
- * 0 = default = 4 = the lean path when M_MAX0 <= 64 (one wave per query, result keys only, the
+ * 0 = default = the lean path when M_MAX0 <= 64 (one wave per query, result keys only, the
  * result heap of hnsw.ts:233-325 replayed from the admission log by a second launch;
- * csrc/traverse_lean.hip.hpp); 1/2/3 force the kernels that keep the result heap inside the
- * traversal on that many waves per query (all bit-identical, tests/test_gpu_traverse_modes.py);
+ * csrc/traverse_lean.hip.hpp); 1 forces the kernel that keeps the result heap inside the
+ * traversal (csrc/traverse.hip.hpp; also what M_MAX0 > 64 and the no-allocation entry point use;
+ * bit-identical, tests/test_gpu_traverse_modes.py);
  * rerank_waves 0 = default (4), 2 = small workgroups that fit beside a running traversal.
  * No reference counterpart. */
 int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves);
@@ -279,6 +280,10 @@ void mvdb_debug_inject_build_failure(mvdb_index *h, int pass);
  * the root (an internal error: never observed)}.  They are answered correctly either way; the counters exist
  * so that tests and benchmarks can tell which kernel ran.  No reference counterpart. */
 void mvdb_lean_fallbacks(const mvdb_index *h, long long *out3);
+/* Queries whose result heap replay_kernel did not have to rebuild / had to rebuild since mvdb_create: out2 =
+ * {short cuts, full replays}.  The short cut applies on the fused path (candidates taken as a set) when no admitted
+ * key equal to the final threshold was evicted; the answers are the same either way.  No reference counterpart. */
+void mvdb_lean_replays(const mvdb_index *h, long long *out2);
 /* Test hook: admissions the lean traversal may log per query (0 = the default, 12 * ef + 1024). */
 void mvdb_debug_set_lean_log_cap(mvdb_index *h, int cap);
 /* Synchronise `stream` and give its per-stream scratch set back (call before

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("mvdb_debug_inject_abort", None, [_vp, _i]),
     ("mvdb_debug_inject_build_failure", None, [_vp, _i]),
     ("mvdb_lean_fallbacks", None, [_vp, _vp]),
+    ("mvdb_lean_replays", None, [_vp, _vp]),
     ("mvdb_debug_set_lean_log_cap", None, [_vp, _i]),
     ("mvdb_release_stream", _i, [_vp, _vp]),
     ("mvdb_enable_timing", None, [_vp, _i]),

@@ -139,6 +139,12 @@ class HipBridge:
         self._L.mvdb_lean_fallbacks(self.handle, out)
         return dict(big_key=out[0], log_full=out[1], mismatch=out[2])
 
+    def leanReplays(self) -> dict:
+        """Queries whose result heap the replay kernel took from the admission log directly / rebuilt (mvdb_lean_replays)."""
+        out = (C.c_longlong * 2)()
+        self._L.mvdb_lean_replays(self.handle, out)
+        return dict(short_cuts=out[0], full_replays=out[1])
+
     def _dim(self) -> int:
         return int(self._cfg["dim"])
 

@@ -31,6 +31,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-fno-fast-math", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
+    cmd += ["-Rpass-analysis=kernel-resource-usage"]  # -> lib/kernel_resources.txt (see check_resources)
     cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     cmd += ["-o", target]
@@ -41,8 +42,46 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed building libmvdb_hip.so")
     if verbose and r.stderr:
-        sys.stderr.write(r.stderr)
+        sys.stderr.write("".join(l for l in r.stderr.splitlines(True) if "kernel-resource-usage" not in l))
+    if out is None:
+        with open(RESOURCES, "w") as f:
+            f.write(_resource_table(r.stderr))
+        check_resources()
     return target
+
+
+RESOURCES = os.path.join(LIB_DIR, "kernel_resources.txt")
+
+
+def _resource_table(stderr: str) -> str:
+    """hipcc's per-kernel remarks -> one line per kernel: name VGPRs AGPRs scratch occupancy."""
+    import re
+    rows, cur = [], None
+    for line in stderr.splitlines():
+        m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "Function Name":
+            cur = [m.group(2)]
+            rows.append(cur)
+        elif cur is not None:
+            cur.append(m.group(2))
+    return "".join(" ".join(r) + "\n" for r in rows if len(r) == 5)
+
+
+def check_resources() -> None:
+    """The lean traversal is latency-bound: its throughput is waves resident x 1 / chain time.  At 384-512 B rows it
+    sits close to 256 VGPRs, where one more live value halves the residency (2 -> 1 waves per SIMD) without any test
+    noticing.  Refuse a build in which that happened, or in which the kernel spills."""
+    import re
+    if not os.path.exists(RESOURCES):
+        return
+    for line in open(RESOURCES):
+        name, vgpr, agpr, scratch, occ = line.split()
+        m = re.match(r"_ZN4mvdb20traverse_lean_kernelILi(\d)ELb[01]EEEvNS_12TraverseArgsE", name)
+        if m and ((int(m.group(1)) <= 4 and int(occ) < 2) or (int(m.group(1)) <= 3 and int(scratch) > 0)):
+            raise RuntimeError(f"{name}: {vgpr} VGPRs + {agpr} AGPRs, {scratch} B scratch, {occ} wave(s) per SIMD -- "
+                               "the lean traversal must keep 2 waves per SIMD up to 512-byte rows, and no scratch up to 384 (see build.py)")
 
 
 if __name__ == "__main__":

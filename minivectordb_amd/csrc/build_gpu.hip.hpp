@@ -28,7 +28,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "traverse_duo.hip.hpp"
+#include "traverse.hip.hpp"
 
 namespace mvdb {
 
@@ -55,6 +55,18 @@ struct BuildArgs {
 	unsigned long long *stats;  // [4] n_dist, n_expanded, n_evictions, n_removed
 };
 
+// minimum / maximum over the wave, in every lane's scalar view (DPP within rows of 16, then 4 readlanes)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
+{
+	auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+	x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+	const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0), b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
+	const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32), d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+	return mn(mn(a, b), mn(c, d));
+}
 __device__ __forceinline__ unsigned wave_max_u32(unsigned x)
 {
 	auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };

@@ -19,7 +19,6 @@
 #include "rerank.hip.hpp"
 #include "scan.hip.hpp"
 #include "traverse.hip.hpp"
-#include "traverse_duo.hip.hpp"
 #include "traverse_lean.hip.hpp"
 #include "build_gpu.hip.hpp"
 
@@ -361,10 +360,11 @@ struct mvdb_index {
 		st_misc, scan_part, prof_buf;
 
 	// tuning knobs of the timed path (mvdb_set_tuning); 0 = the engine's default
-	int traverse_waves = 0;  // 0 / 4: lean kernel + replay (traverse_lean.hip.hpp); 1, 2 or 3: the kernels that keep the result heap in the traversal
+	int traverse_waves = 0;  // 0: lean kernel + replay (traverse_lean.hip.hpp); 1: the one-wave kernel that keeps the result heap in the traversal
 	int lean_log_cap = 0;    // test hook (mvdb_debug_set_lean_log_cap): admissions logged per query, 0 = 12 * ef + 1024
 	int *lean_stats_host = nullptr;  // device-mapped: queries the lean kernel handed to traverse_kernel, by reason
 	int *lean_stats_dev = nullptr;
+	DevBuf replay_stats;             // device: {short cuts, full replays} of replay_kernel (mvdb_lean_replays)
 	int rerank_waves = 0;    // 2 or 4 waves per rerank workgroup
 	// visited-set clean-up (mvdb_set_visited_mode): 0 / 1 = one memset per launch (the default: measured faster at
 	// 1 M and at 10 M nodes), 2 = the kernel's log-and-clear
@@ -455,6 +455,13 @@ int ensure_device(mvdb_index *h)
 		void *dp = nullptr;
 		HIP_OK(h, hipHostGetDevicePointer(&dp, h->lean_stats_host, 0));
 		h->lean_stats_dev = static_cast<int *>(dp);
+	}
+	if (!h->replay_stats.p) {
+		if (!h->replay_stats.need(256)) {
+			h->set_error("out of device memory (counters)");
+			return 0;
+		}
+		HIP_OK(h, hipMemset(h->replay_stats.p, 0, 256));
 	}
 	return 1;
 }
@@ -548,23 +555,6 @@ int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStrea
 	return 1;
 }
 
-template <int J, bool FULL, int WAVES>
-int launch_traverse_duo_w(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
-{
-	static int mark[16] = {0};
-	if (!set_max_lds(h, reinterpret_cast<const void *>(&traverse_duo_kernel<J, FULL, WAVES>), mark, lds)) return 0;
-	hipLaunchKernelGGL((traverse_duo_kernel<J, FULL, WAVES>), dim3(a.nq), dim3(64 * WAVES), lds, s, a);
-	HIP_OK(h, hipGetLastError());
-	return 1;
-}
-
-template <int J, bool FULL>
-int launch_traverse_duo_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
-{
-	if (h->traverse_waves == 2) return launch_traverse_duo_w<J, FULL, 2>(h, a, lds, s);
-	return launch_traverse_duo_w<J, FULL, 3>(h, a, lds, s);
-}
-
 template <int J, bool FULL>
 int launch_traverse_lean_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
 {
@@ -604,7 +594,9 @@ int launch_replay(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 	const size_t lds = replay_lds_bytes(a.ef, may_sort);
 	static int mark[16] = {0};
 	if (!set_max_lds(h, reinterpret_cast<const void *>(&replay_kernel), mark, lds)) return 0;
-	hipLaunchKernelGGL(replay_kernel, dim3(a.nq), dim3(64), lds, s, a, may_sort ? 1 : 0);
+	TraverseArgs r = a;
+	r.lean_stats = static_cast<int *>(h->replay_stats.p);  // replay_kernel counts in device memory
+	hipLaunchKernelGGL(replay_kernel, dim3(a.nq), dim3(64), lds, s, r, may_sort ? 1 : 0);
 	HIP_OK(h, hipGetLastError());
 	return 1;
 }
@@ -613,30 +605,19 @@ int launch_replay(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 // chunk; mvdb_set_tuning(h, 1..3, ..) selects the kernels that keep the result heap inside the traversal.
 bool traverse_use_lean(const mvdb_index *h, const TraverseArgs &a)
 {
-	return a.ix.m0 <= kLeanMaxM0 && (h->traverse_waves == 0 || h->traverse_waves == 4);
+	return a.ix.m0 <= kLeanMaxM0 && h->traverse_waves == 0;
 }
 
-// Several waves per query (traverse_duo.hip.hpp: three by default, mvdb_set_tuning(h, 2, ..) for the
-// two-wave variant) whenever a neighbour list fits one 64-lane chunk; mvdb_set_tuning(h, 1, ..)
-// selects the one-wave kernel for A/B timing.
-bool traverse_use_duo(const mvdb_index *h, const TraverseArgs &a)
+// the one-wave kernel with the result heap inside (traverse.hip.hpp): M_MAX0 > 64, mvdb_set_tuning(h, 1, ..), the
+// queries the lean kernel hands over, and the no-allocation entry point
+int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 {
-	return a.ix.m0 <= kDuoMaxM0 && h->traverse_waves != 1;
-}
-
-int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s, bool one_wave = false)
-{
-	const bool duo = !one_wave && traverse_use_duo(h, a);
-	const size_t lds = duo ? traverse_duo_lds_bytes(a.ef, a.cand_cap) : traverse_lds_bytes(a.ef, a.cand_cap);
+	const size_t lds = traverse_lds_bytes(a.ef, a.cand_cap);
 	const int stride = a.ix.row_stride;
 	const int J = (stride + 127) / 128;
 	const bool full = stride == J * 128;
 #define MVDB_T(JJ)                                                                          \
 	if (J <= JJ) {                                                                          \
-		if (duo) {                                                                          \
-			if (full && J == JJ) return launch_traverse_duo_t<JJ, true>(h, a, lds, s);      \
-			return launch_traverse_duo_t<JJ, false>(h, a, lds, s);                          \
-		}                                                                                   \
 		if (full && J == JJ) return launch_traverse_t<JJ, true>(h, a, lds, s);              \
 		return launch_traverse_t<JJ, false>(h, a, lds, s);                                  \
 	}
@@ -1194,11 +1175,11 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 			TraverseArgs fb = a;
 			fb.only_flagged = a.flag;
 			fb.vis_log = nullptr;
-			if (!launch_traverse(h, fb, s, true)) return 0;
+			if (!launch_traverse(h, fb, s)) return 0;
 			if (!launch_replay(h, a, s)) return 0;
 		} else {
 			StageTimer t(h, 1, s);
-			if (!launch_traverse(h, a, s, false)) return 0;
+			if (!launch_traverse(h, a, s)) return 0;
 		}
 	}
 	return 1;
@@ -1234,7 +1215,7 @@ int mvdb_search_many(mvdb_index *h, const int8_t *q, int nq, int k, int32_t *out
 	if (!mvdb_search_many_dev(h, d_q, nq, k, d_ids, d_dist, d_cnt, d_ctr, nullptr)) return 0;
 	HIP_OK(h, hipDeviceSynchronize());
 	HIP_OK(h, hipMemcpy(out_count, d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
-	if (!check_device_errors(h)) return 0;  // traverse_duo.hip.hpp: a wave gave up waiting, or the pop check failed
+	if (!check_device_errors(h)) return 0;  // a traversal aborted a query (the test hook; no kernel gives up on its own)
 	if (k > 0) {
 		HIP_OK(h, hipMemcpy(out_ids, d_ids, nk * 4, hipMemcpyDeviceToHost));
 		HIP_OK(h, hipMemcpy(out_dist, d_dist, nk * 4, hipMemcpyDeviceToHost));
@@ -1776,8 +1757,8 @@ int mvdb_debug_traverse_profile(mvdb_index *h, unsigned long long *out, int nq)
 #endif
 int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)
 {
-	if (traverse_waves < 0 || traverse_waves > 4 || (rerank_waves != 0 && rerank_waves != 2 && rerank_waves != 4)) {
-		h->set_error("mvdb_set_tuning: traverse_waves must be 0..4, rerank_waves 0, 2 or 4");
+	if (traverse_waves < 0 || traverse_waves > 1 || (rerank_waves != 0 && rerank_waves != 2 && rerank_waves != 4)) {
+		h->set_error("mvdb_set_tuning: traverse_waves must be 0 or 1, rerank_waves 0, 2 or 4");
 		return 0;
 	}
 	h->traverse_waves = traverse_waves;
@@ -1813,6 +1794,14 @@ void mvdb_lean_fallbacks(const mvdb_index *h, long long *out3)
 {
 	for (int i = 0; i < 3; i++)
 		out3[i] = h->lean_stats_host ? (long long)__atomic_load_n(h->lean_stats_host + 1 + i, __ATOMIC_RELAXED) : 0;
+}
+
+void mvdb_lean_replays(const mvdb_index *h, long long *out2)
+{
+	int v[2] = {0, 0};
+	if (h->replay_stats.p && hipMemcpy(v, h->replay_stats.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) v[0] = v[1] = 0;
+	out2[0] = v[0];
+	out2[1] = v[1];
 }
 
 int mvdb_release_stream(mvdb_index *h, void *stream)

@@ -52,14 +52,11 @@ typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
 typedef __attribute__((address_space(3))) u32x2_t lds_u32x2;
 
 // ---- visited set of one query (hnsw.ts:118-132, :494-495) -------------------------------------
-// A private bitmap per query in global memory, zeroed by the launcher per batch.  traverse_kernel / traverse_duo_kernel:
+// A private bitmap per query in global memory, zeroed by the launcher per batch.  traverse_kernel:
 // test-and-set by ONE returning atomicOr per listed neighbour, issued together with its row.  On gfx950 these
 // atomics execute at the memory side (TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r2/pmc_traffic_1m_balanced.json).
 // (The reference's own scheme -- a stamp per node, bumped per search -- was measured as one byte per node with an
 // epoch per launch: bit-exact but slower, 3.03 vs 2.67 ms per 1k-query launch at 1M x 384; see DESIGN.md.)
-#ifndef MVDB_EXP_VIS
-#define MVDB_EXP_VIS 0
-#endif
 struct VisitedSet {
 	uint32_t *p;
 	__device__ __forceinline__ unsigned probe(int id) const { return atomicOr(&p[(unsigned)id >> 5], 1u << (id & 31)); }
@@ -70,19 +67,7 @@ struct VisitedSet {
 	// The caller makes sure its earlier atomics have completed (s_waitcnt vmcnt(0)) before it loads again.
 	__device__ __forceinline__ unsigned load_word(int id) const
 	{
-#if MVDB_EXP_VIS == 2
-		return __hip_atomic_load(&p[(unsigned)id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
 		return __hip_atomic_load(&p[(unsigned)id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-	}
-	__device__ __forceinline__ void set_after(int id, unsigned old) const
-	{
-#if MVDB_EXP_VIS
-		__hip_atomic_store(&p[(unsigned)id >> 5], old | (1u << (id & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-		or_noret(id);
-#endif
 	}
 	__device__ __forceinline__ void or_noret(int id) const
 	{
@@ -452,7 +437,7 @@ struct TraverseArgs {
 	const int *only_flagged;  // traverse_kernel as the fall-back of the lean path: only queries flagged 1..3 run
 };
 
-// An aborted query (traverse_duo's bounded waits, or the test hook) is reported three ways: out_count = -1,
+// An aborted query (the test hook) is reported three ways: out_count = -1,
 // n_found = -1, and bit 0 of the handle's error word, which every host entry point checks after its
 // synchronisation and mvdb_check_errors() exposes to `_dev` callers.
 __device__ __forceinline__ void traverse_report_abort(const TraverseArgs &a, int qi, int lane)

@@ -42,7 +42,7 @@ constexpr unsigned kLeanKeyMax = 65535u;  // 16-bit keys
 constexpr unsigned kLeanInf = 0xffffffffu;
 constexpr int kLeanTake = 48;             // a sparse refill moves at most this many entries into the window
 constexpr int kLeanMaxIn = 12;            // admissions of one list that may join the window on the parallel path (48 + 12 <= 64 lanes)
-constexpr int kLeanLowSlack = 512;        // dead entries the flat key array may hold before it is compacted
+constexpr int kLeanLowSlack = 192;        // dead entries the flat key array may hold before it is compacted (sized so that a replay workgroup fits beside eight traversal workgroups in a CU's LDS at ef 1200)
 
 // flag[qi] after traverse_lean_kernel: what still has to happen to the query
 enum : int {
@@ -136,7 +136,7 @@ __device__ __forceinline__ unsigned lean_shr1(unsigned x, unsigned fill)  // lan
 	return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
 }
 
-// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | flat result keys u16[ef+576] | 5 x 64 dwords of buffers
+// ---- LDS carve: cand keys u16[cap+2] | cand ids u32[cap+2] | flat result keys u16[ef+256] | 5 x 64 dwords of buffers
 struct LeanCarve {
 	unsigned ck, ci, lowk, buf;
 	size_t total;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 					lds_w32(lean_sel(isnew, (unsigned)(size_t)buf_a + 4u * (unsigned)pos, dump), (unsigned)nb);
 					lds_w32(lean_sel(isnew, (unsigned)(size_t)buf_b + 4u * (unsigned)pos, dump), dd);
 				}
-				if (isnew) vis.set_after(nb, old);  // :495, off the chain: nothing waits for it before the next list's words are read
+				if (isnew) vis.or_noret(nb);  // :495, off the chain: nothing waits for it before the next list's words are read
 				MVDB_LANE_JOIN();
 				my_d = buf_b[lane];
 				my_d = lane < n ? my_d : kLeanInf;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				if (n > 0) {
 					lds_w32(lean_sel(isnew, (unsigned)(size_t)buf_a + 4u * (unsigned)__builtin_popcountll(nm & lean_lt_mask(lane)), dump), (unsigned)nb);
 					lean_dist_rows<J, FULL>(ix, Q, buf_a, buf_b, n, c_id, lane, big, dump);  // :497
-					if (isnew) vis.set_after(nb, old);  // :495
+					if (isnew) vis.or_noret(nb);  // :495
 					MVDB_LANE_JOIN();
 					my_d = buf_b[lane];
 					my_d = lane < n ? my_d : kLeanInf;
@@ -931,7 +931,8 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 // (TraverseArgs::set_only).  Reads the log traverse_lean_kernel wrote; queries it flagged are skipped.
 __host__ __device__ inline size_t replay_lds_bytes(int ef, bool sorted)
 {
-	return (size_t)8 * (size_t)((ef + 3) & ~1) + (sorted ? (size_t)8 * (size_t)((ef + 1) & ~1) : 0);
+	const size_t heap = (size_t)8 * (size_t)((ef + 3) & ~1);  // (at least the 256 counters of the short cut's radix select)
+	return (heap < 1024 ? 1024 : heap) + (sorted ? (size_t)8 * (size_t)((ef + 1) & ~1) : 0);
 }
 
 __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_lds)
@@ -949,6 +950,108 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 	rpipe.base = (unsigned)(size_t)res_h;
 	const int n_adm = rfl(a.adm_n[qi]);
 	const uint2 *log = a.adm_log + (size_t)qi * (size_t)(a.adm_log_cap + 64);
+	int32_t *oid = a.out_ids + (size_t)qi * (size_t)a.k;
+	float *od = a.out_dist + (size_t)qi * (size_t)a.k;
+	// ---- short cut when the caller takes the candidates as a SET and none can be cut off (the fused searchMany
+	// path).  The heap only ever evicts its maximum, and its maximum never rises once it is full: every evicted key
+	// is >= every key that stays, so the keys that stay are the `ef` smallest admitted keys, and with W = the
+	// ef-th smallest, every admitted key > W has been evicted and every admitted key < W is still there.  Entries
+	// with key == W are the only ones whose fate depends on where the heap had put them; when exactly `found`
+	// admitted keys are <= W none of them was evicted, and the set is known without any heap.  W by a two-pass
+	// radix select over the 16-bit keys of the log.
+	{
+		const int found0 = n_adm < ef ? n_adm : ef;
+		if (a.set_only && found0 <= a.k && found0 <= a.results_cap && found0 <= MVDB_MAX_EF) {
+			unsigned W = kLeanInf;
+			int n_le = n_adm;
+			if (n_adm > ef) {
+				int *bins = reinterpret_cast<int *>(lds_raw);  // 256 counters (the heap's place: not in use yet)
+				unsigned prefix = 0;                          // high byte of W once known
+				int below = 0;                                // admitted keys below the bin under the lens
+				for (int pass = 0; pass < 2; pass++) {
+					for (int i = lane; i < 256; i += 64) bins[i] = 0;
+					for (int c0 = 0; c0 < n_adm; c0 += 256) {
+						unsigned kx[4];
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							const int i = c0 + u * 64 + lane;
+							kx[u] = i < n_adm ? log[i].x : kLeanInf;
+						}
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							const bool in = kx[u] <= kLeanKeyMax && (pass == 0 || (kx[u] >> 8) == prefix);
+							if (in) atomicAdd(&bins[pass == 0 ? (kx[u] >> 8) : (kx[u] & 255u)], 1);
+						}
+					}
+					// the bin in which the running count reaches ef - below: lane l owns bins 4l .. 4l+3
+					const int b0 = bins[4 * lane], b1 = bins[4 * lane + 1], b2 = bins[4 * lane + 2], b3 = bins[4 * lane + 3];
+					int incl = b0 + b1 + b2 + b3;
+#pragma unroll
+					for (int d = 1; d < 64; d <<= 1) {
+						const int o = __shfl_up(incl, d, 64);
+						incl += lane >= d ? o : 0;
+					}
+					const int need = ef - below;
+					const unsigned long long reach = __ballot(incl >= need);
+					const int wl = __builtin_ctzll(reach);  // (some lane reaches it: n_adm > ef)
+					const int excl = rfl(__shfl(incl - (b0 + b1 + b2 + b3), wl, 64));
+					const int c0_ = rfl(__shfl(b0, wl, 64)), c1_ = rfl(__shfl(b1, wl, 64)), c2_ = rfl(__shfl(b2, wl, 64)),
+					          c3_ = rfl(__shfl(b3, wl, 64));
+					int run = excl, bin = 4 * wl, cnt_bin = c0_;
+					if (run + c0_ < need) {
+						run += c0_;
+						bin++;
+						cnt_bin = c1_;
+						if (run + c1_ < need) {
+							run += c1_;
+							bin++;
+							cnt_bin = c2_;
+							if (run + c2_ < need) {
+								run += c2_;
+								bin++;
+								cnt_bin = c3_;
+							}
+						}
+					}
+					below += run;
+					if (pass == 0) prefix = (unsigned)bin;
+					else {
+						W = (prefix << 8) | (unsigned)bin;
+						n_le = below + cnt_bin;
+					}
+				}
+			}
+			if (n_le == found0) {
+				int pos = 0;
+				for (int c0 = 0; c0 < n_adm; c0 += 256) {
+					uint2 e[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const int i = c0 + u * 64 + lane;
+						e[u] = log[i < n_adm ? i : 0];
+					}
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const bool keep = c0 + u * 64 + lane < n_adm && e[u].x <= W;
+						const unsigned long long km = __ballot(keep);
+						if (keep) {
+							const int o = pos + __builtin_popcountll(km & lean_lt_mask(lane));
+							oid[o] = (int)e[u].y;
+							od[o] = (float)e[u].x;  // keys as the reference holds them: the f32 value of the integer distance (math.ts:126)
+						}
+						pos += __builtin_popcountll(km);
+					}
+				}
+				for (int i = found0 + lane; i < a.k; i += 64) {  // deterministic tail of a ragged row
+					oid[i] = -1;
+					od[i] = 0.f;
+				}
+				if (lane == 0 && a.lean_stats) __hip_atomic_fetch_add(a.lean_stats + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			if (lane == 0 && a.lean_stats) __hip_atomic_fetch_add(a.lean_stats + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
 	int res_size = 0;
 	uint2 cur = lane < n_adm ? log[lane] : make_uint2(0u, 0u);
 	for (int c0 = 0; c0 < n_adm; c0 += 64) {
@@ -974,8 +1077,6 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 	int out_count = found < a.k ? found : a.k;  // :1015-1017
 	if (out_count > a.results_cap) out_count = a.results_cap;
 	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
-	int32_t *oid = a.out_ids + (size_t)qi * (size_t)a.k;
-	float *od = a.out_dist + (size_t)qi * (size_t)a.k;
 	if (unsorted) {
 		for (int i = lane; i < out_count; i += 64) {
 			const uint2 e = res_h[1 + i];

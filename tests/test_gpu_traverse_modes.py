@@ -1,5 +1,5 @@
-"""GPU parity of BOTH traversal kernels (one wave per query, two waves per query) against the oracle
-on shapes chosen to reach the corners of the two-wave protocol: result heap filling up inside a
+"""GPU parity of BOTH traversal paths (the lean kernel + result-heap replay, and the one-wave kernel with the result
+heap inside) against the oracle on shapes chosen to reach their corners: result heap filling up inside a
 list, candidate heap saturated (pushes dropped, hnsw.ts:500), lists of 64 neighbours (two row
 passes), M_MAX0 > 64 (one-wave kernel only), tiny graphs, heavy distance ties."""
 import numpy as np
@@ -41,7 +41,7 @@ def _same(b, ix, q8, k, ef):
     # visited-set clean-up: memset per launch, the kernel's log-and-clear, and the same with a log so short that
     # nearly every query overflows it and zeroes its whole bitmap; every variant twice in a row on the same
     # buffers (the second launch only works on a bitmap the first one left clean)
-    for waves in ("4", "1", "2", "3"):   # 4 = the lean path (the default), 1-3 = result heap inside the traversal
+    for waves in ("0", "1"):   # 0 = the lean path (the default), 1 = result heap inside the traversal
         for mode, cap in ((1, 0), (2, 0), (2, 8), (1, 0)):
             b.setTuning(traverse_waves=int(waves))
             b.setVisitedMode(mode, cap)
@@ -116,7 +116,7 @@ def test_fused_query_path_set_only_output(gpu):
         ix.set_results_cap(4096)
         ids, dist, cnt, _ = ix.search_many(qi, ann_k, threads=8)
         oi, ol, on = O.rerank_many(qf, base, ids, cnt, ann_k, 10, bitmap, 8)
-        for waves in ("4", "1", "2", "3"):
+        for waves in ("0", "1"):
             b.setTuning(traverse_waves=int(waves))
             try:
                 gi, gl, gn = b.queryMany(q, 10, ef, ann_k, allow_bitmap=bitmap)
@@ -147,7 +147,7 @@ def test_aborted_query_is_reported_not_returned_empty(gpu, visited_mode):
     dev = torch.device("cuda", 0)
     s = ResidentSearcher(b, 40, 10, dev)
     q_dev = torch.from_numpy(q).to(dev)
-    for waves in (4, 1, 2, 3):
+    for waves in (0, 1):
         b.setTuning(traverse_waves=waves)
         b._L.mvdb_debug_inject_abort(b.handle, 17)
         with pytest.raises(MvdbError, match="aborted"):

@@ -2,10 +2,10 @@
 
     python tools/occupancy_probe.py [rows] [dim] [ef]
 
-One index, one kernel (three waves per query), batches of 64 ... 5120 queries through mvdb_search_many
-(sorted-list path, stage timer 1 = the traversal launch alone).  256 CUs x 5 workgroups = 1280 resident
+One index, the default (lean) traversal kernel, batches of 64 ... 5120 queries through mvdb_search_many
+(sorted-list path, stage timer 1 = the traversal launch alone).  256 CUs x 8 workgroups = 2048 resident
 queries: below that a launch lasts as long as its slowest query; the per-query figure
-ms / ceil(nq / 1280) tells how much a query slows down when its CU fills up.
+ms / ceil(nq / 2048) tells how much a query slows down when its CU fills up.
 """
 import ctypes as C
 import json

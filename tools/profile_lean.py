@@ -20,7 +20,7 @@ if __name__ == "__main__":
     b = HipBridge(); b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], capacity=n, seed=42, resultsCap=4096))
     qn, q8 = b.prepareQueries(base)
     b.buildGpu(q8)
-    b.setTuning(traverse_waves=4)
+    b.setTuning(traverse_waves=0)
     q = bench.make_queries(1, nq, dim, 54321, qn, clustered)[0]
     _, qi8 = b.prepareQueries(q)
     tk, ef, ann_k = derive_search_params(10, p)

@@ -31,8 +31,7 @@ if __name__ == "__main__":
     b = HipBridge(); b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], capacity=n, seed=42, resultsCap=4096))
     qn, q8 = b.prepareQueries(base)
     b.buildGpu(q8)
-    waves = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    b.setTuning(traverse_waves=waves)
+    b.setTuning(traverse_waves=1)  # the one-wave kernel (tools/profile_lean.py reports the lean kernel's stamps)
     q = (bench.make_queries(1, nq, dim, 54321, qn, True)[0] if clustered
          else np.random.default_rng(54321).standard_normal((nq, dim), dtype=np.float32))
     _, qi8 = b.prepareQueries(q)
@@ -46,33 +45,9 @@ if __name__ == "__main__":
     assert L.mvdb_debug_traverse_profile(b.handle, prof.ctypes.data_as(C.c_void_p), nq)
     print(f"host wall of searchMany (incl. copies): {(t1 - t0) * 1e3:.2f} ms")
     print("counters mean:", ctr.mean(0))
-    if waves == 1:
-        names = ["descent", "cand_pop", "list+visited", "rows+dist", "heap_updates", "final_sort", "output"]
-        print("admitted neighbours per query (mean):", prof[:, 7].mean())
-        tot = prof[:, :7].sum(1).astype(np.float64)
-        print(f"mean cycles/query {tot.mean():.0f}, max {tot.max():.0f}")
-        for i, nm in enumerate(names):
-            print(f"  {nm:14s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %")
-    else:
-        acc = ["descent", "early_mem", "wait_adm+replay", "late_mem", "pop+publish+predict"]
-        resw = ["wait_record", "admission", "final_sort"]
-        print(f"  R cand pushes + wait sift (2 waves) {prof[:, 15].mean():12.0f} cyc")
-        for i, nm in zip(range(16, 20), ["wait message", "wait sift_req", "sift-down", "pushes"]):
-            print(f"  P {nm:20s} {prof[:, i].mean():12.0f} cyc")
-        for i, nm in zip(range(10, 15), ["mem:list", "mem:issue", "mem:background", "mem:rows+dist", "mem:compact"]):
-            print(f"  A {nm:20s} {prof[:, i].mean():12.0f} cyc")
-        hw = prof[:, 20:23].astype(np.int64)
-        simd = (hw >> 4) & 3
-        print("SIMD of (access, result, push) wave, share of queries:")
-        for w, nm in enumerate(["access", "result", "push"]):
-            print(f"  {nm:7s}", " ".join(f"simd{i}: {np.mean(simd[:, w] == i):.2f}" for i in range(4)))
-        combos, cnts = np.unique(simd, axis=0, return_counts=True)
-        print("  combinations:", {tuple(int(x) for x in c): int(n) for c, n in zip(combos, cnts)})
-        ta = prof[:, :5].sum(1).astype(np.float64) + prof[:, 10:15].sum(1).astype(np.float64)
-        tr = prof[:, 5:8].sum(1).astype(np.float64) + prof[:, 15].astype(np.float64)
-        print(f"access wave: mean cycles {ta.mean():.0f} max {ta.max():.0f}; result wave: mean {tr.mean():.0f} max {tr.max():.0f}")
-        print(f"expansions {ctr[:, 1].mean():.0f}  unpredicted {prof[:, 8].mean():.1f}  admitted {prof[:, 9].mean():.0f}")
-        for i, nm in enumerate(acc):
-            print(f"  A {nm:20s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / ta.sum():5.1f} %")
-        for i, nm in enumerate(resw):
-            print(f"  R {nm:20s} {prof[:, 5 + i].mean():12.0f} cyc  {100 * prof[:, 5 + i].sum() / tr.sum():5.1f} %")
+    names = ["descent", "cand_pop", "list+visited", "rows+dist", "heap_updates", "final_sort", "output"]
+    print("admitted neighbours per query (mean):", prof[:, 7].mean())
+    tot = prof[:, :7].sum(1).astype(np.float64)
+    print(f"mean cycles/query {tot.mean():.0f}, max {tot.max():.0f}")
+    for i, nm in enumerate(names):
+        print(f"  {nm:14s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %")
