@@ -501,7 +501,17 @@ def measure(pl, args, steps, warmup, sustain_s, solo):
         # >= 10 windows of >= 20 steps; window durations from stream events, no drain between windows
         nw = 12
         w = max(20, int(math.ceil(sustain_s / max(elapsed / steps, 1e-6) / nw)))
+        bridge._L.mvdb_enable_timing(bridge.handle, 1)
+        s.stage_stats(1)
+        pl.step_i = 0
         el = pl.timed(nw * w, window=w)
+        bridge._L.mvdb_enable_timing(bridge.handle, 0)
+        n_sus, ms_sus = s.stage_stats(1)
+        if n_sus > 0 and ms_sus > 0:   # the same per-launch figure over many more launches than the K timed steps
+            sus_bytes = sum(pl.b_ann[j % pl.nb] for j in range(nw * w)) / (nw * w)
+            roofline["sustained_avg_launch_ms"] = round(ms_sus / n_sus, 4)
+            roofline["sustained_frac"] = round(sus_bytes / (ms_sus / n_sus * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roofline["sustained_launches"] = int(n_sus)
         wm = sorted(x / w for x in pl.window_ms)
         res["sustained"] = dict(value=round(per_step_queries / (el / (nw * w)), 2), unit="queries/s", steps=nw * w,
                                 seconds=round(el, 3), windows=len(wm), steps_per_window=w,

@@ -26,7 +26,7 @@
  *    mvdb_release_stream gives a set back before its stream is destroyed).
  *    mvdb_scan_many_dev uses one scratch set per handle: scans on different
  *    streams must not overlap.
- *  - a traversal that gives up on a query (bounded waits of its wave protocol)
+ *  - a traversal that aborts a query (only the test hook mvdb_debug_inject_abort does)
  *    reports out_count = -1 / out_n = -1 for it and raises the handle's error
  *    word: host entry points then return 0; `_dev` callers call
  *    mvdb_check_errors() after synchronising.

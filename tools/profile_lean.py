@@ -1,5 +1,6 @@
 """Diagnostic: per-phase cycle sums of traverse_lean_kernel (s_memtime stamps, MVDB_TRAVERSE_PROFILE build of the
-library: tools/profile_traverse.py --build).  usage: profile_lean.py [n] [--clustered]"""
+library: tools/profile_traverse.py --build).  usage: profile_lean.py [n] [nq] [--clustered]
+(nq = queries in the launch: 1000 leaves every second place of the chip empty, 2048 fills it)"""
 import ctypes as C, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,7 @@ if __name__ == "__main__":
     if clustered:
         sys.argv.remove("--clustered")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-    nq, dim = 1000, 384
+    nq, dim = (int(sys.argv[2]) if len(sys.argv) > 2 else 1000), 384
     p = resolve_preset("balanced")
     base = bench.make_rows(n, dim, 12345 + (777 if clustered else 0), clustered)
     b = HipBridge(); b.init(dict(dim=dim, m=p["m"], ef=p["ef_construction"], capacity=n, seed=42, resultsCap=4096))
