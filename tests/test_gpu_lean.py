@@ -119,3 +119,54 @@ def test_lean_hands_over_what_it_cannot_hold(gpu):
     assert f["log_full"] > 0 and f["mismatch"] == 0
     b._L.mvdb_debug_set_lean_log_cap(b.handle, 0)
     _check(b, ix, q8, 300, 300, "log back to default")
+
+
+def _fused_equals_oracle(b, ix, base_f32, q_f32, ef, tag):
+    """The fused searchMany path with topK = annK returns EVERY candidate of the traversal (re-ranked): its id set is
+    the candidate set the replay kernel produced -- from the log directly (short cut) or from the rebuilt heap."""
+    qn = O.normalize_rows_f32(q_f32)
+    q8 = O.quantize_rows_i8(qn)
+    ix.set_ef_search(ef)
+    oi, od, oc, _ = ix.search_many(q8, ef, threads=8)
+    e_ids, e_l2, e_n = O.rerank_many(qn, base_f32, oi, oc, ef, ef, threads=8)
+    for rnd in range(2):
+        g_ids, g_l2, g_n = b.queryMany(q_f32, ef, ef, ef)
+        assert np.array_equal(g_n, e_n), f"{tag} ef={ef} round={rnd}: counts differ"
+        bad = np.nonzero((g_ids != e_ids).any(axis=1))[0]
+        assert bad.size == 0, f"{tag} ef={ef} round={rnd}: candidate sets differ in queries {bad[:8]}"
+        assert np.array_equal(g_l2.view(np.uint64), e_l2.view(np.uint64)), f"{tag} ef={ef}"
+
+
+def test_fused_path_candidate_set_with_and_without_the_short_cut(gpu):
+    # the final top-10 of a real query never shows a candidate of rank ~ef: ask for ALL of them (topK = annK = ef)
+    rng = np.random.default_rng(21)
+    # (a) quantised unit vectors: about half of the queries end with an evicted key equal to the threshold
+    base = O.normalize_rows_f32(rng.standard_normal((6000, 64), dtype=np.float32))
+    b8 = O.quantize_rows_i8(base)
+    ix = _index(b8, 64, 16, 100)
+    b = _bridge(ix, 64, 16, 100)
+    b.attachF32(base, resident=True)
+    q = rng.standard_normal((96, 64), dtype=np.float32)
+    for ef in (10, 64, 300, 1200):
+        _fused_equals_oracle(b, ix, base, q, ef, "unit")
+    r = b.leanReplays()
+    assert r["short_cuts"] > 0 and r["full_replays"] > 0, r
+    # (b) a handful of distinct distances: ties at the threshold in nearly every query
+    t8 = (rng.integers(-1, 2, (3000, 16)) * 30).astype(np.int8)
+    tbase = t8.astype(np.float32)
+    ix2 = _index(t8, 16, 16, 60)
+    b2 = _bridge(ix2, 16, 16, 60)
+    b2.attachF32(tbase, resident=True)
+    tq = rng.integers(-1, 2, (64, 16)).astype(np.float32)
+    tq[tq.sum(axis=1) == 0, 0] = 1.0
+    for ef in (10, 64, 500, 1200):
+        _fused_equals_oracle(b2, ix2, tbase, tq, ef, "ties")
+    r2 = b2.leanReplays()
+    assert r2["full_replays"] > 0, r2
+    # (c) fewer admissions than ef: everything admitted survives
+    s8 = O.quantize_rows_i8(O.normalize_rows_f32(rng.standard_normal((150, 32), dtype=np.float32)))
+    sbase = s8.astype(np.float32)
+    ix3 = _index(s8, 32, 8, 40)
+    b3 = _bridge(ix3, 32, 8, 40)
+    b3.attachF32(sbase, resident=True)
+    _fused_equals_oracle(b3, ix3, sbase, rng.standard_normal((32, 32), dtype=np.float32), 400, "small")
