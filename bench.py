@@ -800,7 +800,7 @@ def main():
     ap.add_argument("--leg-deadline-s", type=float, default=330.0,
                     help="the 10m leg is skipped when the run has already taken this long")
     ap.add_argument("--host-f32", action="store_true", help="float32 store in pinned host memory (preloadVectors=false)")
-    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],  # (the engine keeps four per-stream scratch sets)
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
     ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1],
                     help="0 = the engine's default (lean traversal + result-heap replay); 1 = the one-wave kernel with the result heap inside")

@@ -276,12 +276,11 @@ __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const Que
 
 // diagnostic stamps (MVDB_TRAVERSE_PROFILE builds only), slots: 0 query + descent, 1 list + issue of the memory
 // phase, 2 candidate-heap work in the shadow of the loads, 3 rows + distances, 4 visited test + compaction,
-// 5 admission (6 = the refills inside it), 7 log + prediction; counters: 8 lists not prefetched, 9 admitted
+// 5 admission (6 = the refills inside it), 7 log + prediction, 16-18 + 2 = the heap work split into pushes, root check,
+// sift-down, new root + list request; 13 = from the compaction to the admission loop (list prefetch of the nearest new
+// neighbour, filling phase), 14 parallel decision, 15 its inserts, 19 one-at-a-time iterations, 20 refills; counters: 21 one-at-a-time
+// admissions, 22 lists decided in parallel, 8 lists not prefetched, 9 admitted
 // neighbours, 10 refills, 11 of them dense, 12 expansions whose next candidate came out of the list itself
-#ifdef MVDB_LEAN_MARK  // instruction-count study: phase boundaries show up in the assembly listing (never shipped)
-#undef MVDB_STAMP
-#define MVDB_STAMP(slot) asm volatile("; LEANMARK " #slot)
-#endif
 #ifdef MVDB_TRAVERSE_PROFILE
 #define MVDB_LEAN_COUNT(slot, v) prof_acc[slot] += (unsigned long long)(v)
 #else
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		return;
 	}
 #ifdef MVDB_TRAVERSE_PROFILE
-	unsigned long long prof_acc[16] = {};
+	unsigned long long prof_acc[24] = {};
 	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -650,6 +649,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				cand.push(cand_size++, (unsigned)__builtin_amdgcn_readlane(p_id, t), lean_readlane(p_d, t), lane);
 			}
 			pend = 0;
+			MVDB_STAMP(16);
 			unsigned lk, li;
 			{
 				unsigned rk, ri;  // root and last entry in one round trip
@@ -665,8 +665,10 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				}
 			}
 			cand_size--;
+			MVDB_STAMP(17);
 			if (cand_size > 0) {
 				cand.sift_root(cand_size, li, lk, lane);
+				MVDB_STAMP(18);
 				{
 					unsigned ok_, oi_;
 					lds_r16_r32(cand.kb + 2u, cand.ib + 4u, ok_, oi_);
@@ -796,15 +798,16 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 					need_refill = true;
 				}
 			}
+			MVDB_STAMP(13);
 			for (;;) {
 				if (need_refill) {
 					refill();
 					if (bail >= 0) break;
 					worst = win.worst();
 					need_refill = false;
+					MVDB_STAMP(20);
 				}
 				if (!rem || res_size < ef) break;
-				MVDB_STAMP(13);
 				const unsigned long long B = lean_uni64(__ballot(my_d < worst) & rem);  // `worst` only falls: the others stay rejected
 				const int nB = __builtin_popcountll(B);
 				if (nB == 0) break;
@@ -824,6 +827,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 					if (bail >= 0) break;
 					if (ok & ~inwin) low_append(ok & ~inwin, my_d);
 					MVDB_STAMP(15);
+					MVDB_LEAN_COUNT(22, 1);
 					win.remove_largest(__builtin_popcountll(ok), lane);  // :506-507 every replace_root drops the largest key
 					adm |= ok;
 					rem = 0;
@@ -842,6 +846,8 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				win.remove_largest(1, lane);
 				if (d >= win.T) win_insert(d);
 				else low_append(1ull << t, my_d);
+				MVDB_STAMP(19);
+				MVDB_LEAN_COUNT(21, 1);
 				if (bail >= 0) break;
 				if (win.V == 0) {
 					need_refill = true;
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
 #ifdef MVDB_TRAVERSE_PROFILE
 	if (lane == 0 && a.prof)
-		for (int i = 0; i < 16; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
+		for (int i = 0; i < 24; i++) a.prof[(size_t)qi * kProfSlots + i] = prof_acc[i];
 #endif
 	if (lane == 0) {
 		a.flag[qi] = kLeanDone;

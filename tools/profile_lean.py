@@ -36,12 +36,19 @@ if __name__ == "__main__":
     print("counters mean:", ctr.mean(0))
     names = ["query+descent", "list+issue", "heap work (shadow)", "rows+dist", "visited+compact", "admission (incl refill)",
              "  of which refill", "log+predict"]
-    tot = prof[:, [0, 1, 2, 3, 4, 5, 7]].sum(1).astype(np.float64)
+    heap_parts = prof[:, [16, 17, 18, 2]].astype(np.float64)   # pushes | root + last, check | sift-down | new root, list request
+    prof[:, 2] += prof[:, 16] + prof[:, 17] + prof[:, 18]      # slot 2 = the whole heap work in the table below
+    tot = prof[:, [0, 1, 2, 3, 4, 5, 7, 13, 14, 15, 19, 20]].sum(1).astype(np.float64)
     ex = ctr[:, 1].mean()
     print(f"mean cycles/query {tot.mean():.0f} max {tot.max():.0f}; expansions {ex:.0f} -> {tot.mean() / ex:.0f} cycles per expansion")
     for i, nm in enumerate(names):
-        print(f"  {nm:26s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %   {prof[:, i].mean() / ex:8.0f} /expansion")
-    for i, nm in zip(range(13, 16), ["adm: up to B", "adm: in-window test", "adm: inserts + append"]):
-        print(f"  {nm:28s} {prof[:, i].mean() / ex:10.0f} cycles per expansion")
-    for i, nm in zip(range(8, 13), ["lists not prefetched", "admitted", "refills", "dense refills", "next candidate from the list"]):
+        if i != 6:
+            print(f"  {nm:26s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %   {prof[:, i].mean() / ex:8.0f} /expansion")
+    for i, nm in enumerate(["heap: pushes", "heap: root + last, check", "heap: sift-down", "heap: new root, list request"]):
+        print(f"  {nm:28s} {heap_parts[:, i].mean() / ex:10.0f} cycles per expansion")
+    for i, nm in zip([13, 14, 15, 19, 20, 5], ["adm: prefetch + preamble", "adm: parallel decision", "adm: inserts + append", "adm: one-at-a-time path",
+                                             "adm: refills", "adm: remove largest, log"]):
+        print(f"  {nm:28s} {prof[:, i].mean() / ex:10.0f} cycles per expansion   {100 * prof[:, i].sum() / tot.sum():5.1f} %")
+    for i, nm in zip([8, 9, 10, 11, 12, 21, 22], ["lists not prefetched", "admitted", "refills", "dense refills", "next candidate from the list",
+                                                 "admitted one at a time", "lists decided in parallel"]):
         print(f"  {nm:28s} {prof[:, i].mean():10.1f} per query")
