@@ -60,6 +60,8 @@ enum : int {
 // dword of a dump area), loads a valid address and discards the value.  Where a branch remains (global atomics),
 // an empty volatile asm behind it keeps its join block apart from the enclosing uniform one.
 #define MVDB_LANE_JOIN() asm volatile("")
+// block placement: the hot path of an expansion should fall through (a taken branch costs a lone wave a refetch)
+#define MVDB_RARE(c) __builtin_expect(!!(c), 0)
 
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		int n = 0;
 		unsigned my_d = kLeanInf;
 		int my_id = -1;
-		if (first) {
+		if (MVDB_RARE(first)) {
 			n = 1;  // :453-454
 			my_d = lane == 0 ? cur_d : kLeanInf;
 			my_id = lane == 0 ? cur : -1;
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				ri = (unsigned)rfl((int)ri);
 				lk = (unsigned)rfl((int)lk);
 				li = (unsigned)rfl((int)li);
-				if (cand_size <= 0 || (int)ri != c_id || rk != c_d) {
+				if (MVDB_RARE(cand_size <= 0 || (int)ri != c_id || rk != c_d)) {
 					bail = kLeanMismatch;
 					break;
 				}
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 						lds_w32(lean_sel(sl == 0 && slot0[pp] < cnt, (unsigned)(size_t)all_dist + 4u * (unsigned)slot0[pp], dump), tot);
 					}
 				}
-				if (cnt > 32) {  // lists of up to 64 neighbours: a second pass
+				if (MVDB_RARE(cnt > 32)) {  // lists of up to 64 neighbours: a second pass
 					int4 v1[4][J];
 					int slot1[4];
 #pragma unroll
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				seen_listed += cnt - (seen_listed >> 2);
 				seen_new += n - (seen_new >> 2);
 			}
-			if (__ballot(big)) {
+			if (MVDB_RARE(__ballot(big) != 0ull)) {
 				bail = kLeanBigKey;
 				break;
 			}
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		if (n > 0) {
 			unsigned long long rem = n >= 64 ? ~0ull : ((1ull << n) - 1);
 			bool need_refill = false;
-			if (res_size < ef) {  // :504-505 while the result set fills up everything is admitted
+			if (MVDB_RARE(res_size < ef)) {  // :504-505 while the result set fills up everything is admitted
 				const int f = n < ef - res_size ? n : ef - res_size;
 				lds_w16(lean_sel(lane < f, lowk + 2u * (unsigned)(low_n + lane), dump), my_d);
 				low_n += f;
@@ -800,9 +802,9 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			}
 			MVDB_STAMP(13);
 			for (;;) {
-				if (need_refill) {
+				if (MVDB_RARE(need_refill)) {
 					refill();
-					if (bail >= 0) break;
+					if (MVDB_RARE(bail >= 0)) break;
 					worst = win.worst();
 					need_refill = false;
 					MVDB_STAMP(20);
@@ -824,14 +826,14 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 					ok = lean_uni64(ok);
 					MVDB_STAMP(14);
 					for (unsigned long long mm = ok & inwin; mm; mm &= mm - 1) win_insert(lean_readlane(my_d, __builtin_ctzll(mm)));
-					if (bail >= 0) break;
+					if (MVDB_RARE(bail >= 0)) break;
 					if (ok & ~inwin) low_append(ok & ~inwin, my_d);
 					MVDB_STAMP(15);
 					MVDB_LEAN_COUNT(22, 1);
 					win.remove_largest(__builtin_popcountll(ok), lane);  // :506-507 every replace_root drops the largest key
 					adm |= ok;
 					rem = 0;
-					if (win.V == 0) {
+					if (MVDB_RARE(win.V == 0)) {
 						need_refill = true;
 						continue;
 					}
@@ -848,18 +850,18 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				else low_append(1ull << t, my_d);
 				MVDB_STAMP(19);
 				MVDB_LEAN_COUNT(21, 1);
-				if (bail >= 0) break;
-				if (win.V == 0) {
+				if (MVDB_RARE(bail >= 0)) break;
+				if (MVDB_RARE(win.V == 0)) {
 					need_refill = true;
 					continue;
 				}
 				worst = win.worst();
 			}
-			if (bail >= 0) break;
+			if (MVDB_RARE(bail >= 0)) break;
 			adm = lean_uni64(adm);
 			const int na = __builtin_popcountll(adm);
 			MVDB_LEAN_COUNT(9, na);
-			if (n_adm + na > a.adm_log_cap) {
+			if (MVDB_RARE(n_adm + na > a.adm_log_cap)) {
 				bail = kLeanLogFull;
 				break;
 			}
