@@ -188,7 +188,6 @@ class Pipeline:
         q_seed = 54321 + (rank if (world > 1 and not sharded) else 0)
         self.q_host = make_queries(self.nb, self.nq, self.dim, q_seed, self.base, clustered)
         self.q_dev = torch.from_numpy(self.q_host).to(dev)
-        self.bridge.setVisitedMode(args.visited_mode)
         self.searcher = s = ResidentSearcher(self.bridge, self.nq, self.tk, dev)
         # the host side of a step ("H2D/D2H of queries/results included"): pinned query batches,
         # one device staging buffer and one pinned result block per batch in flight
@@ -804,8 +803,6 @@ def main():
                     help="batches in flight: batch i runs on stream i %% IN_FLIGHT; 1 = one batch at a time")
     ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1],
                     help="0 = the engine's default (lean traversal + result-heap replay); 1 = the one-wave kernel with the result heap inside")
-    ap.add_argument("--visited-mode", type=int, default=0, choices=[0, 1, 2],
-                    help="visited-bitmap clean-up: 0 / 1 memset per launch (default), 2 the kernel's log-and-clear (measured slower)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="wiring rehearsal of the N>1 path on a one-GPU box: every rank uses cuda:0 and the exchange "
                          "goes over gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing")

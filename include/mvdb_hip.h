@@ -254,14 +254,6 @@ int mvdb_merge_topk_packed_dev(mvdb_index *h, const void *d_blocks, int parts, i
  * rerank_waves 0 = default (4), 2 = small workgroups that fit beside a running traversal.
  * No reference counterpart. */
 int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves);
-/* How the per-query visited bitmaps (hnsw.ts:480-495: the reference's visited stamps) get back to
- * zero between launches: 0 / 1 = one hipMemsetAsync per launch (N/8 bytes per query; the default),
- * 2 = the traversal kernel logs the ids it marks and zeroes exactly those words when the query is
- * done (a query whose log overflows log_cap ids, or that aborts, zeroes its whole bitmap); log_cap
- * 0 = 65536.  Results are identical; mode 2 measured 8-9 % slower at 1 M and at 10 M nodes (the
- * log rides on the access wave's critical path) and is kept for hosts that cannot afford the
- * 1.25 GB memset per 1 k-query batch of a 10 M-node index sharing their stream. */
-int mvdb_set_visited_mode(mvdb_index *h, int mode, int log_cap);
 /* After the caller synchronised its stream(s): 1 = no kernel of this handle raised the
  * error word since the last check, 0 = one did (mvdb_last_error has the text).  Clears it.
  * The WASM cannot fail this way; the reference's nearest analogue is the abort import

@@ -75,7 +75,6 @@ SYMBOLS = [
     ("mvdb_topk_block_bytes", _sz, [_i, _i]),
     ("mvdb_merge_topk_packed_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     ("mvdb_set_tuning", _i, [_vp, _i, _i]),
-    ("mvdb_set_visited_mode", _i, [_vp, _i, _i]),
     ("mvdb_check_errors", _i, [_vp]),
     ("mvdb_upload_counters", None, [_vp, _vp]),
     ("mvdb_debug_inject_abort", None, [_vp, _i]),

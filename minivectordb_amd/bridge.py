@@ -118,10 +118,6 @@ class HipBridge:
         with self._lock:
             self._check(self._L.mvdb_set_tuning(self.handle, int(traverse_waves), int(rerank_waves)))
 
-    def setVisitedMode(self, mode: int = 0, log_cap: int = 0):
-        """0 / 1 memset per launch (default), 2 log-and-clear (mvdb_set_visited_mode)."""
-        self._check(self._L.mvdb_set_visited_mode(self.handle, int(mode), int(log_cap)))
-
     def checkErrors(self) -> None:
         """After synchronising `_dev` work: raise if a kernel of this handle reported a failure."""
         with self._lock:

@@ -339,11 +339,8 @@ struct mvdb_index {
 	struct StreamScratch {
 		hipStream_t stream = nullptr;
 		bool used = false;
-		DevBuf visited, vis_log, qf, q8, ids, dist, cnt;
+		DevBuf visited, qf, q8, ids, dist, cnt;
 		DevBuf adm_log, adm_n, flag;   // traverse_lean_kernel -> replay_kernel
-		bool vis_clean = false;        // the first vis_clean_bytes of `visited` are zero (log mode leaves them so)
-		size_t vis_clean_bytes = 0;
-		void *vis_seen_ptr = nullptr;  // the allocation `vis_clean` speaks of
 	} ss[kStreamSets];
 	int ss_next = 0;  // round-robin victim when every set is taken
 	// Host slots (mvdb_query_many_submit / _wait): a stream of its own, pinned host staging and device
@@ -366,10 +363,6 @@ struct mvdb_index {
 	int *lean_stats_dev = nullptr;
 	DevBuf replay_stats;             // device: {short cuts, full replays} of replay_kernel (mvdb_lean_replays)
 	int rerank_waves = 0;    // 2 or 4 waves per rerank workgroup
-	// visited-set clean-up (mvdb_set_visited_mode): 0 / 1 = one memset per launch (the default: measured faster at
-	// 1 M and at 10 M nodes), 2 = the kernel's log-and-clear
-	int visited_mode = 0;
-	int visited_log_cap = 0;  // ids per query, 0 = kVisitedLogCap
 	// error word the kernels raise (host-pinned, device-mapped): bit 0 = a traversal aborted a query
 	int *err_host = nullptr;
 	int *err_dev = nullptr;
@@ -1048,8 +1041,6 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	a.results_cap = h->g.results_cap;
 	a.set_only = set_only ? 1 : 0;
 	a.vis_stride = visited_stride_bytes(h->g.max_elements);
-	a.vis_log = nullptr;  // memset mode unless the caller sets a log up
-	a.vis_log_cap = 0;
 	a.adm_log = nullptr;  // lean path only (search_many_dev_impl)
 	a.adm_log_cap = 0;
 	a.adm_n = a.flag = a.lean_stats = nullptr;
@@ -1076,7 +1067,6 @@ mvdb_index::StreamScratch *scratch_for(mvdb_index *h, hipStream_t s)
 	return &c;
 }
 
-constexpr int kVisitedLogCap = 64 << 10;                    // logged ids per query (a balanced query marks ~18 k)
 
 // shared by mvdb_search_many_dev (sorted lists, the bridge contract) and the fused query path
 // (set_only: see TraverseArgs)
@@ -1105,18 +1095,7 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		h->set_error("out of device memory (visited sets)");
 		return 0;
 	}
-	// bitmap clean-up: per-launch memset, or the kernel's own log-and-clear (VisitedLog) for large indexes
-	const bool lean = traverse_use_lean(h, a);  // the lean kernel always works on a bitmap the launcher zeroed
-	const bool log_mode = h->visited_mode == 2 && !lean;
-	a.vis_log = nullptr;
-	a.vis_log_cap = h->visited_log_cap > 0 ? h->visited_log_cap : kVisitedLogCap;
-	if (log_mode) {
-		a.vis_log = static_cast<uint32_t *>(sc->vis_log.need((size_t)slab * (size_t)a.vis_log_cap * 4));
-		if (!a.vis_log) {
-			h->set_error("out of device memory (visited logs)");
-			return 0;
-		}
-	}
+	const bool lean = traverse_use_lean(h, a);
 	// lean path: the traversal logs its admissions, replay_kernel rebuilds the result heap from the log
 	a.adm_log = nullptr;
 	a.adm_log_cap = 0;
@@ -1138,19 +1117,7 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	for (int q0 = 0; q0 < nq; q0 += slab) {
 		const int n = std::min(slab, nq - q0);
 		const size_t need = (size_t)n * a.vis_stride;
-		if (log_mode) {
-			// zero once after (re)allocation or after a memset-mode launch; every log-mode launch leaves it zero
-			if (!sc->vis_clean || sc->vis_seen_ptr != vis || sc->vis_clean_bytes < need) {
-				HIP_OK(h, hipMemsetAsync(vis, 0, need, s));
-				sc->vis_seen_ptr = vis;
-				sc->vis_clean = true;
-				sc->vis_clean_bytes = need;
-			}
-		} else {
-			HIP_OK(h, hipMemsetAsync(vis, 0, need, s));
-			sc->vis_seen_ptr = vis;
-			sc->vis_clean = false;  // the launch leaves its marks behind
-		}
+		HIP_OK(h, hipMemsetAsync(vis, 0, need, s));  // the visited bitmaps of this launch
 		a.q = d_q + (size_t)q0 * g.cfg.dim;
 		a.nq = n;
 		a.visited = vis;
@@ -1174,7 +1141,6 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 			// result heap inside, on the bitmaps those queries left clean; every other workgroup leaves at once
 			TraverseArgs fb = a;
 			fb.only_flagged = a.flag;
-			fb.vis_log = nullptr;
 			if (!launch_traverse(h, fb, s)) return 0;
 			if (!launch_replay(h, a, s)) return 0;
 		} else {
@@ -1763,17 +1729,6 @@ int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves)
 	}
 	h->traverse_waves = traverse_waves;
 	h->rerank_waves = rerank_waves;
-	return 1;
-}
-
-int mvdb_set_visited_mode(mvdb_index *h, int mode, int log_cap)
-{
-	if (mode < 0 || mode > 2 || log_cap < 0 || log_cap > (1 << 22)) {
-		h->set_error("mvdb_set_visited_mode: mode must be 0 (default), 1 (memset per launch) or 2 (log and clear), log_cap 0..4194304");
-		return 0;
-	}
-	h->visited_mode = mode;
-	h->visited_log_cap = log_cap;
 	return 1;
 }
 

@@ -83,64 +83,6 @@ __host__ __device__ inline size_t visited_stride_bytes(int max_elements)
 	return (((size_t)max_elements + 31) / 32 * 4 + 255) & ~(size_t)255;
 }
 
-// Clean-up by log instead of a memset per batch (mvdb_set_visited_mode(h, 2, cap); NOT the default).  The
-// bitmap of a 10 M-node index is 1.25 MB per query, 1.25 GB per 1 k-query batch, 0.55 ms of hipMemsetAsync
-// per 3.1 ms step, while a query sets ~18 k bits of it.  Here the wave that owns the visited set logs
-// every node it marks (coalesced stores, list by list) and zeroes exactly those words when the query
-// is done; a query whose log overflows, or that aborts, zeroes its whole bitmap instead.  The buffer
-// is zero when a launch starts and zero again when it ends; the host clears it only after
-// (re)allocation.  Measured (three batches in flight): 1 M 404 k -> 367 k queries/s, 10 M 323 k -> 296 k:
-// the memset runs beside the other batches' traversals for free, the log does not.
-struct VisitedLog {
-	uint32_t *log;  // this query's log, null = the host clears the bitmaps (memset mode)
-	int cap, pos;
-	bool overflow;
-	__device__ __forceinline__ void init(uint32_t *base, int cap_, int qi)
-	{
-		log = base ? base + (size_t)qi * (size_t)cap_ : nullptr;
-		cap = cap_;
-		pos = 0;
-		overflow = false;
-	}
-	// `isnew` lanes append `id` at pos + rank (nm = ballot(isnew), n = popcount(nm)); wave-uniform bookkeeping
-	__device__ __forceinline__ void append(bool isnew, int id, unsigned long long nm, int n, int lane)
-	{
-		if (!log || n == 0) return;
-		if (pos + n > cap) {
-			overflow = true;
-			return;
-		}
-		if (isnew) log[pos + __builtin_popcountll(nm & ((1ull << lane) - 1))] = (uint32_t)id;
-		pos += n;
-	}
-	__device__ __forceinline__ void append_one(int id, int lane)
-	{
-		if (!log) return;
-		if (pos + 1 > cap) {
-			overflow = true;
-			return;
-		}
-		if (lane == 0) log[pos] = (uint32_t)id;
-		pos += 1;
-	}
-	// zero what this query marked (bitmap = its vis_stride bytes, a multiple of 256)
-	__device__ __forceinline__ void clear(uint32_t *bitmap, size_t stride_bytes, bool everything, int lane) const
-	{
-		if (!log) return;
-		if (everything || overflow) {
-			uint4 *p = reinterpret_cast<uint4 *>(bitmap);
-			const size_t n16 = stride_bytes / 16;
-			for (size_t i = lane; i < n16; i += 64) p[i] = make_uint4(0u, 0u, 0u, 0u);
-			return;
-		}
-		for (int i = lane; i < pos; i += 64) {
-			// the log was written by other lanes of this wave: read it past the vector L1
-			const uint32_t id = __hip_atomic_load(&log[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			bitmap[id >> 5] = 0u;
-		}
-	}
-};
-
 // ---- 1-based array heaps in LDS ------------------------------------------------
 // MIN = candidate min-heap (hnsw.ts:153-213), !MIN = result max-heap (:233-315).
 // Entry p = {key, id} (8 bytes); children 2p, 2p+1 are one aligned 16-byte LDS read.
@@ -418,8 +360,6 @@ struct TraverseArgs {
 	int nq, k, ef, cand_cap, results_cap;
 	int set_only;         // 1: the caller only needs the SET of candidates (see traverse_emit_unsorted)
 	void *visited;        // nq x vis_stride bytes, see VisitedSet
-	uint32_t *vis_log;    // nq x vis_log_cap marked ids (VisitedLog) or null: the host clears the bitmaps per launch
-	int vis_log_cap;
 	size_t vis_stride;    // bytes per query
 	int32_t *out_ids;     // nq x k
 	float *out_dist;      // nq x k
@@ -573,15 +513,12 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 	MVDB_STAMP(0);  // query load + descent
 	// search_layer(query, cur, 0, ef, false): hnsw.ts:423-523
 	const VisitedSet vis{reinterpret_cast<decltype(VisitedSet::p)>(static_cast<unsigned char *>(a.visited) + (size_t)qi * a.vis_stride)};
-	VisitedLog vlog;
-	vlog.init(a.vis_log, a.vis_log_cap, qi);
 	int cand_size = 0, res_size = 0;
 	{
 		// dist0 (:450) re-evaluates the row the descent ended on: same value, counted, not re-read
 		const unsigned d0 = cur_d;
 		n_dist++;
 		if (lane == 0) vis.mark(cur);  // :452
-		vlog.append_one(cur, lane);
 		cand.push(cand_size++, cur, d0, lane);                                 // :453
 		res.push(res_size++, cur, d0, lane);                                   // :454
 	}
@@ -627,7 +564,6 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 			if (isnew) vis.set(nb);
 			const unsigned long long nm = __ballot(isnew);
 			const int n = __builtin_popcountll(nm);
-			vlog.append(isnew, nb, nm, n, lane);
 			MVDB_STAMP(2);  // neighbour list + visited test-and-set
 			if (__ballot(nb >= 0) == 0) break;
 			if (n == 0) continue;
@@ -719,7 +655,6 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 			a.ctr[qi] = c;
 		}
 	}
-	vlog.clear(vis.p, a.vis_stride, false, lane);
 }
 
 }  // namespace mvdb
