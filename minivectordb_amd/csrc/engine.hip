@@ -539,8 +539,15 @@ void resolve_stage(mvdb_index *h, int stage)
 }
 
 template <int J, bool FULL>
-int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s)
+int launch_traverse_t(mvdb_index *h, const TraverseArgs &a, size_t lds, hipStream_t s, bool flagged)
 {
+	if (flagged) {  // the fall-back launch of the lean path: the queries listed in a.fb_list
+		static int fmark[16] = {0};
+		if (!set_max_lds(h, reinterpret_cast<const void *>(&traverse_flagged_kernel<J, FULL>), fmark, lds)) return 0;
+		hipLaunchKernelGGL((traverse_flagged_kernel<J, FULL>), dim3(std::min(a.nq, 32)), dim3(64), lds, s, a);
+		HIP_OK(h, hipGetLastError());
+		return 1;
+	}
 	static int mark[16] = {0};
 	if (!set_max_lds(h, reinterpret_cast<const void *>(&traverse_kernel<J, FULL>), mark, lds)) return 0;
 	hipLaunchKernelGGL((traverse_kernel<J, FULL>), dim3(a.nq), dim3(64), lds, s, a);
@@ -603,7 +610,7 @@ bool traverse_use_lean(const mvdb_index *h, const TraverseArgs &a)
 
 // the one-wave kernel with the result heap inside (traverse.hip.hpp): M_MAX0 > 64, mvdb_set_tuning(h, 1, ..), the
 // queries the lean kernel hands over, and the no-allocation entry point
-int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
+int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s, bool flagged = false)
 {
 	const size_t lds = traverse_lds_bytes(a.ef, a.cand_cap);
 	const int stride = a.ix.row_stride;
@@ -611,8 +618,8 @@ int launch_traverse(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 	const bool full = stride == J * 128;
 #define MVDB_T(JJ)                                                                          \
 	if (J <= JJ) {                                                                          \
-		if (full && J == JJ) return launch_traverse_t<JJ, true>(h, a, lds, s);              \
-		return launch_traverse_t<JJ, false>(h, a, lds, s);                                  \
+		if (full && J == JJ) return launch_traverse_t<JJ, true>(h, a, lds, s, flagged);     \
+		return launch_traverse_t<JJ, false>(h, a, lds, s, flagged);                         \
 	}
 	MVDB_T(1)
 	MVDB_T(2)
@@ -1044,7 +1051,7 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	a.adm_log = nullptr;  // lean path only (search_many_dev_impl)
 	a.adm_log_cap = 0;
 	a.adm_n = a.flag = a.lean_stats = nullptr;
-	a.only_flagged = nullptr;
+	a.fb_list = a.fb_n = nullptr;
 	a.prof = nullptr;
 }
 
@@ -1101,18 +1108,20 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 	a.adm_log_cap = 0;
 	a.adm_n = a.flag = nullptr;
 	a.lean_stats = h->lean_stats_dev;
-	a.only_flagged = nullptr;
+	a.fb_list = a.fb_n = nullptr;
 	if (lean) {
 		a.adm_log_cap = h->lean_log_cap > 0 ? h->lean_log_cap : 12 * a.ef + 1024;
 		const size_t per_q = (size_t)(a.adm_log_cap + 64) * sizeof(uint2);  // + 64: where masked-off lanes of a log store write
 		slab = (int)std::min<size_t>((size_t)slab, std::max<size_t>(1, ((size_t)2 << 30) / per_q));  // <= 2 GiB of logs per stream
 		a.adm_log = static_cast<uint2 *>(sc->adm_log.need((size_t)slab * per_q));
 		a.adm_n = static_cast<int *>(sc->adm_n.need((size_t)slab * 4));
-		a.flag = static_cast<int *>(sc->flag.need((size_t)slab * 4));
+		a.flag = static_cast<int *>(sc->flag.need(((size_t)2 * slab + 1) * 4));  // flags | list of handed-over queries | its length
 		if (!a.adm_log || !a.adm_n || !a.flag) {
 			h->set_error("out of device memory (admission logs)");
 			return 0;
 		}
+		a.fb_list = a.flag + slab;
+		a.fb_n = a.flag + 2 * slab;
 	}
 	for (int q0 = 0; q0 < nq; q0 += slab) {
 		const int n = std::min(slab, nq - q0);
@@ -1132,16 +1141,15 @@ int search_many_dev_impl(mvdb_index *h, const int8_t *d_q, int nq, int k, int32_
 		a.prof = static_cast<unsigned long long *>(h->prof_buf.need((size_t)nq * kProfSlots * 8)) + (size_t)q0 * kProfSlots;
 #endif
 		if (lean) {
+			HIP_OK(h, hipMemsetAsync(a.fb_n, 0, 4, s));
 			{
 				StageTimer t(h, 1, s);  // brackets the traversal kernel only
 				if (!launch_traverse_lean(h, a, s)) return 0;
 			}
 			StageTimer t(h, 4, s);
 			// queries the lean kernel gave up on (a distance beyond 16 bits, a full log): the one-wave kernel with the
-			// result heap inside, on the bitmaps those queries left clean; every other workgroup leaves at once
-			TraverseArgs fb = a;
-			fb.only_flagged = a.flag;
-			if (!launch_traverse(h, fb, s)) return 0;
+			// result heap inside, on the bitmaps those queries left clean -- a few workgroups that walk the list
+			if (!launch_traverse(h, a, s, true)) return 0;
 			if (!launch_replay(h, a, s)) return 0;
 		} else {
 			StageTimer t(h, 1, s);

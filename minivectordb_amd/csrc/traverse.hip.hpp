@@ -374,7 +374,7 @@ struct TraverseArgs {
 	int *adm_n;           // nq: entries logged
 	int *flag;            // nq: kLeanDone, or why the query is left to traverse_kernel
 	int *lean_stats;      // device-mapped host counters of the handle, indexed by flag value, or null
-	const int *only_flagged;  // traverse_kernel as the fall-back of the lean path: only queries flagged 1..3 run
+	int *fb_list, *fb_n;  // queries traverse_lean_kernel hands to traverse_flagged_kernel (flags 1..3), and their number
 };
 
 // An aborted query (the test hook) is reported three ways: out_count = -1,
@@ -420,17 +420,11 @@ __host__ __device__ inline size_t traverse_lds_bytes(int ef, int cand_cap)
 	return (size_t)8 * (size_t)((ef + 3) & ~1) + (size_t)8 * (size_t)((cand_cap + 3) & ~1) + (size_t)4 * 3 * 64;
 }
 
+// one query, start to finish, by the calling wave (the workgroup's dynamic LDS at lds_raw)
 template <int J, bool FULL>
-__global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
+__device__ __forceinline__ void traverse_query(const TraverseArgs &a, const int qi, unsigned char *lds_raw)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
-	const int qi = blockIdx.x;
-	if (qi >= a.nq) return;
-	if (a.only_flagged) {  // fall-back launch behind traverse_lean_kernel
-		const int f = rfl(a.only_flagged[qi]);
-		if (f < 1 || f > 3) return;
-	}
 	const DevIndexView &ix = a.ix;
 	if (qi == a.inject_abort_q) {  // test hook: the one-wave kernel has no abort path of its own
 		traverse_report_abort(a, qi, lane);
@@ -655,6 +649,26 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 			a.ctr[qi] = c;
 		}
 	}
+}
+
+template <int J, bool FULL>
+__global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const int qi = blockIdx.x;
+	if (qi >= a.nq) return;
+	traverse_query<J, FULL>(a, qi, lds_raw);
+}
+
+// The fall-back launch behind traverse_lean_kernel: a handful of workgroups walk the list of queries the lean kernel
+// handed over (fb_list[0 .. *fb_n), usually empty: the launch then costs a few idle workgroups, not one per query
+// each asking for this kernel's 30 KB of LDS).
+template <int J, bool FULL>
+__global__ __launch_bounds__(64) void traverse_flagged_kernel(TraverseArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const int n = rfl(__hip_atomic_load(a.fb_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	for (int i = blockIdx.x; i < n; i += gridDim.x) traverse_query<J, FULL>(a, rfl(a.fb_list[i]), lds_raw);
 }
 
 }  // namespace mvdb

@@ -907,6 +907,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		}
 		if (lane == 0) {
 			a.flag[qi] = bail;
+			if (bail >= kLeanBigKey && bail <= kLeanMismatch) a.fb_list[atomicAdd(a.fb_n, 1)] = qi;
 			if (a.lean_stats) __hip_atomic_fetch_add(a.lean_stats + bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		return;
