@@ -20,12 +20,11 @@
  *    every bridge call behind a promise-chain mutex, wasm-bridge.ts:39-50).
  *  - `_dev` entry points are issued from ONE host thread at a time, but their
  *    work may overlap on the device: mvdb_query_many_dev, mvdb_search_many_dev,
- *    mvdb_prepare_queries_dev, mvdb_rerank_many_dev and mvdb_merge_topk_dev keep
- *    their intermediates per stream (up to 4 streams; a fifth stream takes over
- *    the least recently assigned set after that set's stream has drained;
- *    mvdb_release_stream gives a set back before its stream is destroyed).
- *    mvdb_scan_many_dev uses one scratch set per handle: scans on different
- *    streams must not overlap.
+ *    mvdb_prepare_queries_dev, mvdb_rerank_many_dev, mvdb_merge_topk_dev and
+ *    mvdb_scan_many_dev keep their intermediates per stream (up to 4 streams; a
+ *    fifth stream takes over the least recently assigned set after that set's
+ *    stream has drained; mvdb_release_stream gives a set back before its stream
+ *    is destroyed).
  *  - a traversal that aborts a query (only the test hook mvdb_debug_inject_abort does)
  *    reports out_count = -1 / out_n = -1 for it and raises the handle's error
  *    word: host entry points then return 0; `_dev` callers call

@@ -341,6 +341,7 @@ struct mvdb_index {
 		bool used = false;
 		DevBuf visited, qf, q8, ids, dist, cnt;
 		DevBuf adm_log, adm_n, flag;   // traverse_lean_kernel -> replay_kernel
+		DevBuf scan_part;              // mvdb_scan_many_dev: partial lists, bounds
 	} ss[kStreamSets];
 	int ss_next = 0;  // round-robin victim when every set is taken
 	// Host slots (mvdb_query_many_submit / _wait): a stream of its own, pinned host staging and device
@@ -354,7 +355,7 @@ struct mvdb_index {
 		bool busy = false;
 	} hs[kStreamSets];
 	DevBuf st_q8, st_qf, st_ids, st_dist, st_cnt, st_ctr, st_allow, st_out_ids, st_out_l2, st_out_n,
-		st_misc, scan_part, prof_buf;
+		st_misc, prof_buf;
 
 	// tuning knobs of the timed path (mvdb_set_tuning); 0 = the engine's default
 	int traverse_waves = 0;  // 0: lean kernel + replay (traverse_lean.hip.hpp); 1: the one-wave kernel that keeps the result heap in the traversal
@@ -1632,7 +1633,7 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	}
 	const size_t part_elems = (size_t)nq * a.nslots * k;
 	const size_t part_bytes = part_elems * 8 + (((size_t)nq * a.nslots * 4 + 7) & ~(size_t)7);
-	unsigned char *part = static_cast<unsigned char *>(h->scan_part.need(part_bytes + (size_t)nq * 8));
+	unsigned char *part = static_cast<unsigned char *>(scratch_for(h, s)->scan_part.need(part_bytes + (size_t)nq * 8));
 	if (!part) {
 		h->set_error("out of device memory (scan scratch)");
 		return 0;

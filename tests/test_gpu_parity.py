@@ -281,3 +281,39 @@ def test_scan_many_wide_levels(gpu, dim, rows, slots, nq, k, metric, coarse):
     assert np.array_equal(gi, oi)
     assert np.array_equal(gv, ov)
     b.close()
+
+
+def test_scans_on_two_streams_overlap(gpu):
+    """mvdb_scan_many_dev keeps its partial lists and bounds per stream: two sweeps with different queries queued on two
+    streams at once (several rounds, so that they do run side by side) each return the oracle's exhaustive result."""
+    import ctypes as C
+    import torch
+    from minivectordb_amd import HipBridge
+    n, dim, nq, k = 20000, 128, 300, 10
+    rng = np.random.default_rng(77)
+    b8 = O.quantize_rows_i8(O.normalize_rows_f32(rng.standard_normal((n, dim), dtype=np.float32)))
+    ix = O.OracleIndex(dim, 2, 4, n, seed=5)
+    ix.insert_many(np.arange(n, dtype=np.int32), b8)
+    b = HipBridge()
+    b.init(dict(dim=dim, m=2, ef=4, capacity=8, seed=1))
+    b.loadBytes(ix.save_bytes())
+    b.scanMany(b8[:4], k, "l2")                              # uploads the index
+    dev = torch.device("cuda", 0)
+    qs = [O.quantize_rows_i8(O.normalize_rows_f32(rng.standard_normal((nq, dim), dtype=np.float32))) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    qd = [torch.from_numpy(q).to(dev) for q in qs]
+    outs = [(torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.int32, device=dev),
+             torch.empty((nq,), dtype=torch.int32, device=dev)) for _ in range(2)]
+    torch.cuda.synchronize(dev)
+    vp = C.c_void_p
+    for rnd in range(6):
+        for j in range(2):
+            b._check(b._L.mvdb_scan_many_dev(b.handle, vp(qd[j].data_ptr()), nq, k, 0, vp(outs[j][0].data_ptr()),
+                                             vp(outs[j][1].data_ptr()), vp(outs[j][2].data_ptr()), vp(streams[j].cuda_stream)))
+    torch.cuda.synchronize(dev)
+    for j in range(2):
+        oi, ov, oc = ix.scan_many(qs[j], k, "l2", threads=8)
+        assert np.array_equal(outs[j][2].cpu().numpy(), oc)
+        assert np.array_equal(outs[j][0].cpu().numpy(), oi) and np.array_equal(outs[j][1].cpu().numpy(), ov)
+    b.close()
+    ix.close()
