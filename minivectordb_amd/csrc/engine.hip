@@ -1626,10 +1626,11 @@ int mvdb_scan_many_dev(mvdb_index *h, const int8_t *d_q, int nq, int k, int metr
 	a.nodes_per_split = 0;
 	a.level0 = kScanLevel0;
 	a.level_ratio = kScanLevelRatio;
+	a.wide_ratio = kScanWideRatio;
 	a.qtiles = a.s2 = a.nsplit = 0;  // per level (scan_plan)
 	{
 		ScanLevel plan[kScanMaxLevels];
-		scan_plan(N, nq, a.wide, a.seed, a.level0, a.level_ratio, plan, &a.nslots);
+		scan_plan(N, nq, a.wide, a.seed, a.level0, a.level_ratio, a.wide_ratio, plan, &a.nslots);
 	}
 	const size_t part_elems = (size_t)nq * a.nslots * k;
 	const size_t part_bytes = part_elems * 8 + (((size_t)nq * a.nslots * 4 + 7) & ~(size_t)7);

@@ -51,7 +51,7 @@ struct ScanArgs {
 	int nodes_per_split;     // multiple of kScanStage (per level, set by the launcher)
 	int node_lo, node_hi;    // node range of this level
 	int slot0, nslots;       // partial-list slot of split 0 of this level; slots per query over all levels
-	int level0, level_ratio; // level plan (scan_levels)
+	int level0, level_ratio, wide_ratio; // level plan (scan_levels)
 	int seed;                // 1: level 0 goes to scan_seed_kernel (see scan_plan)
 	int wide;                // > 0: levels of at least this many nodes go to scan_wide_kernel (k <= kWideMaxK); see scan_plan
 	unsigned long long *thr_g;     // [nq] smallest k-th key published by any split, ~0 before the launch
@@ -615,18 +615,22 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(ScanArgs a, int slots_u
 constexpr int kScanLevel0 = 1024;   // nodes of the first level (no bound yet)
 constexpr int kScanLevelRatio = 8;  // each later level ends at ratio x its start
 constexpr int kScanMaxLevels = 16;
+// the levels the wide kernel takes grow by this factor (it pays more per candidate than scan_kernel, but ~100 us per
+// launch: measured at 1 M x 512, 4096 queries: x2 2.08 ms, x3 2.04, x4 2.01, x6 2.02, x16 2.20 per sweep)
+constexpr int kScanWideRatio = 4;
 
 // ends[i] = end of level i (multiples of kScanStage, last = N); returns the number of levels.
-// fine_from > 0: where the next level at `ratio` would hold at least that many nodes, levels only double -- the
-// wide kernel takes those, pays more per candidate than scan_kernel, and a doubling level brings ~k candidates
-// per query instead of ~k (ratio - 1).
-__host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 = kScanLevel0, int ratio = kScanLevelRatio, int fine_from = 0)
+// fine_from > 0: where the next level at `ratio` would hold at least that many nodes, levels grow by fine_ratio only --
+// the wide kernel takes those, pays more per candidate than scan_kernel, and a level of x r brings ~k (r - 1)
+// candidates per query.
+__host__ inline int scan_levels(int N, int (&ends)[kScanMaxLevels], int level0 = kScanLevel0, int ratio = kScanLevelRatio, int fine_from = 0,
+                               int fine_ratio = kScanWideRatio)
 {
 	int n = 0;
 	long long e = level0;
 	while (e < N && n < kScanMaxLevels - 1) {
 		ends[n++] = (int)e;
-		e *= (fine_from > 0 && e * (ratio - 1) >= fine_from) ? 2 : ratio;
+		e *= (fine_from > 0 && e * (ratio - 1) >= fine_from) ? fine_ratio : ratio;
 	}
 	ends[n++] = N;
 	return n;
@@ -646,10 +650,11 @@ struct ScanLevel {
 };
 constexpr int kWideMinLevel = 100000;
 
-__host__ inline int scan_plan(int N, int nq, int wide, int seed, int level0, int ratio, ScanLevel (&lv)[kScanMaxLevels], int *total_slots)
+__host__ inline int scan_plan(int N, int nq, int wide, int seed, int level0, int ratio, int wide_ratio, ScanLevel (&lv)[kScanMaxLevels],
+                             int *total_slots)
 {
 	int ends[kScanMaxLevels];
-	const int levels = scan_levels(N, ends, level0, ratio, wide);
+	const int levels = scan_levels(N, ends, level0, ratio, wide, wide_ratio);
 	int lo = 0, slot = 0;
 	for (int l = 0; l < levels; l++) {
 		ScanLevel &v = lv[l];
@@ -696,7 +701,7 @@ inline bool launch_scan_t(const ScanArgs &a0, hipStream_t s)
 	if (a0.wide && (!HAS_WIDE || a0.k > kWideMaxK)) return false;
 	ScanLevel lv[kScanMaxLevels];
 	int total = 0;
-	const int levels = scan_plan(a0.ix.max_elements, a0.nq, a0.wide, a0.seed, a0.level0, a0.level_ratio, lv, &total);
+	const int levels = scan_plan(a0.ix.max_elements, a0.nq, a0.wide, a0.seed, a0.level0, a0.level_ratio, a0.wide_ratio, lv, &total);
 	if (total > a0.nslots) return false;
 	ScanArgs a = a0;
 	for (int l = 0; l < levels; l++) {
