@@ -221,3 +221,27 @@ def test_python_bridge_rejects_wrong_shapes():
                  lambda: b.setTuning(traverse_waves=7)):
         with pytest.raises(MvdbError):
             call()
+
+
+def test_build_records_kernel_resources_and_the_lean_kernel_keeps_its_residency():
+    """minivectordb_amd/build.py writes every kernel's registers / scratch / occupancy next to the library and refuses a
+    build whose lean traversal lost its second wave per SIMD (a regression no functional test sees: one live value more
+    took it from 206 to 257 VGPRs and the bench from 403 k to 325 k queries/s).  The record must be there and the guard must fire on a doctored record."""
+    from minivectordb_amd import build as B
+    assert os.path.exists(B.RESOURCES), "lib/kernel_resources.txt missing: build with python -m minivectordb_amd.build"
+    rows = {l.split()[0]: l.split()[1:] for l in open(B.RESOURCES)}
+    lean = "_ZN4mvdb20traverse_lean_kernelILi3ELb1EEEvNS_12TraverseArgsE"      # 384-byte rows, the benchmarked shape
+    assert lean in rows and int(rows[lean][3]) >= 2 and int(rows[lean][2]) == 0, rows.get(lean)
+    B.check_resources()
+    good = B.RESOURCES
+    try:
+        bad = good + ".doctored"
+        with open(bad, "w") as f:
+            f.write(open(good).read().replace(lean + " " + " ".join(rows[lean]), lean + " 257 0 0 1"))
+        B.RESOURCES = bad
+        with pytest.raises(RuntimeError):
+            B.check_resources()
+    finally:
+        B.RESOURCES = good
+        if os.path.exists(good + ".doctored"):
+            os.remove(good + ".doctored")
