@@ -6,7 +6,7 @@ import random
 
 TAKE = 48
 MAXIN = 12
-SLACK = 512
+SLACK = 192
 INF = 1 << 16
 
 
