@@ -279,8 +279,7 @@ __device__ __forceinline__ void lean_dist_rows(const DevIndexView &ix, const Que
 // diagnostic stamps (MVDB_TRAVERSE_PROFILE builds only), slots: 0 query + descent, 1 list + issue of the memory
 // phase, 2 candidate-heap work in the shadow of the loads, 3 rows + distances, 4 visited test + compaction,
 // 5 admission (6 = the refills inside it), 7 log + prediction, 16-18 + 2 = the heap work split into pushes, root check,
-// sift-down, new root + list request; 13 = from the compaction to the admission loop (list prefetch of the nearest new
-// neighbour, filling phase), 14 parallel decision, 15 its inserts, 19 one-at-a-time iterations, 20 refills; counters: 21 one-at-a-time
+// sift-down, new root + list request; 13 = from the compaction to the admission loop (filling phase), 14 parallel decision, 15 its inserts, 19 one-at-a-time iterations, 20 refills; counters: 21 one-at-a-time
 // admissions, 22 lists decided in parallel, 8 lists not prefetched, 9 admitted
 // neighbours, 10 refills, 11 of them dense, 12 expansions whose next candidate came out of the list itself
 #ifdef MVDB_TRAVERSE_PROFILE
@@ -566,7 +565,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	int c_id = cur;  // the candidate to expand next, known before the heap has seen it
 	unsigned c_d = cur_d;
 	int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
-	int pre2_id = -1, pre2_nb = -1;  // list fetched ahead for the nearest new neighbour of the last list
 	int seen_listed = 0, seen_new = 0;  // decaying counts: rows with the visited test while at least half were new
 	int o_id = -1;
 	unsigned o_key = 0;
@@ -597,7 +595,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		o_id = rfl(o_id);                               \
 		o_key = (unsigned)rfl((int)o_key);              \
 		pref_id = rfl(pref_id);                         \
-		pre2_id = rfl(pre2_id);                         \
 		seen_listed = rfl(seen_listed);                 \
 		seen_new = rfl(seen_new);                       \
 		n_l0 = rfl(n_l0);                               \
@@ -617,7 +614,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			// are needed -- masking at the load would wait for it on the spot)
 			int nb = -1;
 			if (pref_id == c_id) nb = pref_nb;
-			else if (pre2_id == c_id) nb = pre2_nb;
 			else {
 				nb = ix.adj0[(size_t)c_id * (size_t)m0 + lane_m0];
 				MVDB_LEAN_COUNT(8, 1);
@@ -756,18 +752,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			}
 			n_l0++;
 			n_dist += n;
-			// The nearest new neighbour is popped next whenever it is admitted and undercuts the root the pop left (see
-			// below): its list is asked for NOW, so that it travels while the list is being admitted.  A hint only.
-			if (n > 0) {
-				const unsigned dm = lean_wave_min(my_d);
-				if ((res_size < ef || dm < worst) && (cand_size == 0 || dm < o_key)) {
-					const int g_id = __builtin_amdgcn_readlane(my_id, __builtin_ctzll(__ballot(my_d == dm)));
-					if (g_id != pref_id && g_id != pre2_id) {
-						pre2_id = g_id;
-						pre2_nb = ix.adj0[(size_t)g_id * (size_t)m0 + lane_m0];
-					}
-				}
-			}
 		}
 		first = false;
 		n = rfl(n);

@@ -46,7 +46,7 @@ if __name__ == "__main__":
             print(f"  {nm:26s} {prof[:, i].mean():12.0f} cyc  {100 * prof[:, i].sum() / tot.sum():5.1f} %   {prof[:, i].mean() / ex:8.0f} /expansion")
     for i, nm in enumerate(["heap: pushes", "heap: root + last, check", "heap: sift-down", "heap: new root, list request"]):
         print(f"  {nm:28s} {heap_parts[:, i].mean() / ex:10.0f} cycles per expansion")
-    for i, nm in zip([13, 14, 15, 19, 20, 5], ["adm: prefetch + preamble", "adm: parallel decision", "adm: inserts + append", "adm: one-at-a-time path",
+    for i, nm in zip([13, 14, 15, 19, 20, 5], ["adm: preamble", "adm: parallel decision", "adm: inserts + append", "adm: one-at-a-time path",
                                              "adm: refills", "adm: remove largest, log"]):
         print(f"  {nm:28s} {prof[:, i].mean() / ex:10.0f} cycles per expansion   {100 * prof[:, i].sum() / tot.sum():5.1f} %")
     for i, nm in zip([8, 9, 10, 11, 12, 21, 22], ["lists not prefetched", "admitted", "refills", "dense refills", "next candidate from the list",
