@@ -564,7 +564,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 	int p_id = -1;
 	int c_id = cur;  // the candidate to expand next, known before the heap has seen it
 	unsigned c_d = cur_d;
-	int pref_id = -1, pref_nb = -1;  // list fetched ahead for the root the last pop left
 	int seen_listed = 0, seen_new = 0;  // decaying counts: rows with the visited test while at least half were new
 	int o_id = -1;
 	unsigned o_key = 0;
@@ -594,7 +593,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 		c_d = (unsigned)rfl((int)c_d);                  \
 		o_id = rfl(o_id);                               \
 		o_key = (unsigned)rfl((int)o_key);              \
-		pref_id = rfl(pref_id);                         \
 		seen_listed = rfl(seen_listed);                 \
 		seen_new = rfl(seen_new);                       \
 		n_l0 = rfl(n_l0);                               \
@@ -612,12 +610,14 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 			if (res_size >= ef && c_d > worst) break;  // :466 (strict >)
 			// (every lane loads, lanes beyond the list re-read its last entry; the mask is applied HERE, where the words
 			// are needed -- masking at the load would wait for it on the spot)
-			int nb = -1;
-			if (pref_id == c_id) nb = pref_nb;
-			else {
-				nb = ix.adj0[(size_t)c_id * (size_t)m0 + lane_m0];
-				MVDB_LEAN_COUNT(8, 1);
+			int nb = ix.adj0[(size_t)c_id * (size_t)m0 + lane_m0];
+			// ---- candidate-heap work, first half, under the list load: the pushes the previous list admitted (:500-502)
+			for (unsigned long long m = lean_uni64(pend); m; m &= m - 1) {
+				const int t = __builtin_ctzll(m);
+				cand.push(cand_size++, (unsigned)__builtin_amdgcn_readlane(p_id, t), lean_readlane(p_d, t), lane);
 			}
+			pend = 0;
+			MVDB_STAMP(16);
 			nb = lane < m0 ? nb : -1;
 			const int cnt = __builtin_popcountll(__ballot(nb >= 0));  // canonical lists: valid prefix
 			// ---- issue the memory phase: visited test-and-set (:494-495) and, while at least half of the recently
@@ -640,14 +640,7 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 				}
 			}
 			MVDB_STAMP(1);
-			// ---- candidate-heap work of this expansion, under the loads: the pushes the previous list admitted
-			// (:500-502), then cand_pop of this candidate (:460) and the fetch of the list of the root it leaves
-			for (unsigned long long m = lean_uni64(pend); m; m &= m - 1) {
-				const int t = __builtin_ctzll(m);
-				cand.push(cand_size++, (unsigned)__builtin_amdgcn_readlane(p_id, t), lean_readlane(p_d, t), lane);
-			}
-			pend = 0;
-			MVDB_STAMP(16);
+			// ---- candidate-heap work, second half, under the row loads: cand_pop of this candidate (:460)
 			unsigned lk, li;
 			{
 				unsigned rk, ri;  // root and last entry in one round trip
@@ -672,10 +665,6 @@ __global__ __launch_bounds__(64) void traverse_lean_kernel(TraverseArgs a)
 					lds_r16_r32(cand.kb + 2u, cand.ib + 4u, ok_, oi_);
 					o_key = (unsigned)rfl((int)ok_);
 					o_id = rfl((int)oi_);
-				}
-				if (pref_id != o_id) {  // needed next unless a new neighbour undercuts it
-					pref_id = o_id;
-					pref_nb = ix.adj0[(size_t)o_id * (size_t)m0 + lane_m0];
 				}
 			}
 			MVDB_STAMP(2);
