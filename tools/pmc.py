@@ -52,7 +52,7 @@ def cmd_traffic(src, out, tag):
         if line.startswith("{"):
             info = json.loads(line)
     assert info, "pmc_run.py summary line missing"
-    keep, cal, trv, kname = [], {}, {}, ""
+    keep, cal, trv, kname, cal_ns = [], {}, {}, "", []
     for name in ("fetch", "write", "rdreq", "hit"):
         files = csvs(os.path.join(src, f"pmc_{name}"))
         assert files, f"no counter csv for pass {name}"
@@ -66,6 +66,7 @@ def cmd_traffic(src, out, tag):
             c = [r for r in rows if r["Counter_Name"] == cname and "dist_pairs_kernel" in r["Kernel_Name"]]
             t = [r for r in main if r["Counter_Name"] == cname][-3:]
             keep += c + t
+            cal_ns += [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in c]
             cal[cname] = sum(float(r["Counter_Value"]) for r in c)
             trv[cname] = sum(float(r["Counter_Value"]) for r in t) / max(len(t), 1)
             kname = t[-1]["Kernel_Name"] if t else kname
@@ -88,7 +89,11 @@ def cmd_traffic(src, out, tag):
                     "(tools/pmc_run.py under tools/pmc_passes.sh)",
         "calibration": {"kernel": "dist_pairs_kernel", "known_bytes": known, "fetch_size_bytes": cal["FETCH_SIZE"] * 1024.0,
                         "correction": corr, "rdreq_breakdown_bytes": rd_bytes(cal), "rdreq_correction": rd_corr,
-                        "note": "same 8-lanes-x-16-B row gather as the traversal; gfx950 FETCH_SIZE reads ~1/2 of such streams"},
+                        "note": "same 8-lanes-x-16-B row gather as the traversal; gfx950 FETCH_SIZE reads ~1/2 of such streams",
+                        # what the chip delivers on this access pattern and nothing else: the practical ceiling of a
+                        # kernel that gathers random 384-byte rows (launch durations from the same csv rows)
+                        "duration_ms": sum(cal_ns) / len(cal_ns) * 1e-6,
+                        "random_row_gather_gbs": known / (sum(cal_ns) / len(cal_ns) * 1e-9) / 1e9},
         "traverse": {
             "kernel": kernel_of(kname), "launches": 3, "algorithmic_bytes_per_launch": alg,
             "fetch_size_bytes_per_launch": fetch, "read_bytes_per_launch": reads,
