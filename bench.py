@@ -812,8 +812,8 @@ def run_scan(args, torch, dist, dev, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hnsw", choices=["hnsw", "scan"])
     # (--rows: torchrun's own parser trips over "--n" in the script's arguments)
     ap.add_argument("--n", "--rows", dest="n", type=int, default=None, help="vectors per index (per shard when sharded); default 1M")

@@ -13,7 +13,7 @@ prof() {  # name, bench args...
   find "$O/prof_$name" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats_$name.csv" \;
 }
 prof 1m_balanced --legs none --cpu-sample 0 --no-pcie &&
-python3 "$R/tools/kernel_trace_table.py" "$(find "$O/prof_1m_balanced" -name '*kernel_trace.csv' | head -1)" traverse_lean_kernel reference:8,warmup:3,timed:20,solo:16,resident:20,sustained:* "$O/traverse_launches_1m_balanced.csv" > "$O/traverse_launches_summary.txt" &&
+python3 "$R/tools/kernel_trace_table.py" "$(find "$O/prof_1m_balanced" -name '*kernel_trace.csv' | head -1)" traverse_lean_kernel reference:8,warmup:5,timed:100,solo:16,resident:100,sustained:* "$O/traverse_launches_1m_balanced.csv" > "$O/traverse_launches_summary.txt" &&
 prof scan_1m_512 --workload scan --cpu-sample 0 --second-dataset none &&
 prof 10m_balanced --rows 10000000 --legs none --cpu-sample 0 --no-pcie --no-recall &&
 find "$O" -name "*kernel_trace.csv" -delete &&
