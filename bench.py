@@ -54,6 +54,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+RANDOM_ROW_GBS = 6490.0  # random 384-byte rows over 4 GiB, 8 lanes x 16 B x 3, nothing else: tools/micro/probe_rate.hip, profiles/r3/probe_rate_random_4B_loads.txt
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2x the ~2.5 PF dense bf16 rate (same guide, Matrix cores)
 CLUSTERS, CLUSTER_SIGMA, CLUSTER_QUERY_SIGMA = 4096, 0.35, 0.05
 
@@ -425,9 +426,8 @@ def traffic_record(pl, kernel):
                 doc = json.load(fh)
             rec = doc.get("traverse", {})
             if rec.get("kernel") == kernel and "corrected_bytes_per_launch" in rec:
-                return (int(rec["corrected_bytes_per_launch"]), f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of this workload)",
-                        doc.get("calibration", {}).get("random_row_gather_gbs"))
-    return None, None, None
+                return int(rec["corrected_bytes_per_launch"]), f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of this workload)"
+    return None, None
 
 
 def measure(pl, args, steps, warmup, sustain_s, solo):
@@ -462,7 +462,7 @@ def measure(pl, args, steps, warmup, sustain_s, solo):
     achieved = bytes_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
     m0 = 2 * pl.preset["m"]
     kernel = "traverse_kernel" if (m0 > 64 or args.traverse_waves == 1) else "traverse_lean_kernel"
-    traffic, traffic_source, gather_gbs = traffic_record(pl, kernel)
+    traffic, traffic_source = traffic_record(pl, kernel)
     roofline = dict(bound="hbm", kernel=kernel, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(bytes_per_launch), avg_launch_ms=round(trav_ms, 4),
@@ -513,12 +513,12 @@ def measure(pl, args, steps, warmup, sustain_s, solo):
             roofline["sustained_avg_launch_ms"] = round(ms_sus / n_sus, 4)
             roofline["sustained_frac"] = round(sus_bytes / (ms_sus / n_sus * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             roofline["sustained_launches"] = int(n_sus)
-        if traffic and gather_gbs:
+        if traffic:
             # what the memory side moves per second with the batches overlapping (PMC bytes of a traversal launch + the
-            # rerank's rows, x batches per second), beside what the chip delivers on random 384-byte row gathers alone
+            # rerank's rows, x batches per second), beside what it delivers on random 384-byte rows and nothing else
             roofline["chip_traffic_gbs_sustained"] = round((traffic + roofline["rerank_bytes_per_launch"]) / (el / (nw * w)) / 1e9, 1)
-            roofline["random_row_gather_gbs"] = round(gather_gbs, 1)
-            roofline["chip_traffic_over_gather_rate"] = round(roofline["chip_traffic_gbs_sustained"] / gather_gbs, 4)
+            roofline["random_row_rate_gbs"] = RANDOM_ROW_GBS
+            roofline["chip_traffic_over_random_row_rate"] = round(roofline["chip_traffic_gbs_sustained"] / RANDOM_ROW_GBS, 4)
         wm = sorted(x / w for x in pl.window_ms)
         res["sustained"] = dict(value=round(per_step_queries / (el / (nw * w)), 2), unit="queries/s", steps=nw * w,
                                 seconds=round(el, 3), windows=len(wm), steps_per_window=w,

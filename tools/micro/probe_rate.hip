@@ -30,19 +30,61 @@ __device__ __forceinline__ unsigned ld(const unsigned *p)
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(const unsigned *buf, unsigned words_mask, int iters, unsigned *out)
 {
-	unsigned x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+	unsigned x = ((blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u) | 1u;
 	unsigned acc = 0;
 	for (int i = 0; i < iters; i++) {
 		unsigned v[8];
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
-			x = x * 1664525u + 1013904223u;
-			v[u] = ld<MODE>(buf + ((x >> 4) & words_mask));
+			x ^= x << 13, x ^= x >> 17, x ^= x << 5;  // xorshift32
+			v[u] = ld<MODE>(buf + (x & words_mask));
 		}
 #pragma unroll
 		for (int u = 0; u < 8; u++) acc += v[u];
 	}
 	if (acc == 0x12345678u) out[0] = acc;
+}
+
+// random 384-byte rows the way the traversal reads them: 8 lanes x 16 bytes x 3 pieces per row, 4 rows in flight per lane group
+__global__ __launch_bounds__(256) void rows384(const uint4 *buf, unsigned rows, int iters, unsigned *out)
+{
+	unsigned x = (((blockIdx.x * 256u + threadIdx.x) >> 3) * 2654435761u + 12345u) | 1u;
+	const int s = threadIdx.x & 7;
+	unsigned acc = 0;
+	for (int i = 0; i < iters; i++) {
+		uint4 v[4][3];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+			const uint4 *r = buf + (size_t)(x % rows) * 24 + s;
+#pragma unroll
+			for (int j = 0; j < 3; j++) v[u][j] = r[8 * j];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+#pragma unroll
+			for (int j = 0; j < 3; j++) acc += v[u][j].x ^ v[u][j].y ^ v[u][j].z ^ v[u][j].w;
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+
+void run_rows(const unsigned *buf, size_t bytes, unsigned *out)
+{
+	const int blocks = 256 * 8, iters = 256;
+	const unsigned rows = (unsigned)(bytes / 384);
+	hipEvent_t a, b;
+	CK(hipEventCreate(&a));
+	CK(hipEventCreate(&b));
+	rows384<<<blocks, 256>>>((const uint4 *)buf, rows, 8, out);
+	CK(hipDeviceSynchronize());
+	CK(hipEventRecord(a));
+	rows384<<<blocks, 256>>>((const uint4 *)buf, rows, iters, out);
+	CK(hipEventRecord(b));
+	CK(hipDeviceSynchronize());
+	float ms;
+	CK(hipEventElapsedTime(&ms, a, b));
+	const double n = (double)blocks * 32 * iters * 4;
+	printf("%-28s %8.3f ms  %7.2f G rows/s    (x384 B = %6.2f TB/s)\n", "random 384-byte rows", ms, n / ms * 1e-6, n * 384 / ms * 1e-9);
 }
 
 template <int MODE>
@@ -67,7 +109,7 @@ void run(const char *name, const unsigned *buf, unsigned mask, unsigned *out)
 
 int main()
 {
-	const size_t bytes = (size_t)1 << 30;  // 1 GiB: past the L2s and the Infinity Cache
+	const size_t bytes = (size_t)4 << 30;  // 4 GiB: the L2s (32 MB) and the Infinity Cache (256 MB) hold 7 % of it
 	unsigned *buf, *out;
 	CK(hipMalloc(&buf, bytes));
 	CK(hipMalloc(&out, 256));
@@ -79,6 +121,7 @@ int main()
 	run<3>("sc0 sc1 nt", buf, mask, out);
 	run<4>("sc1 nt", buf, mask, out);
 	run<5>("ubyte sc1", buf, mask, out);
+	run_rows(buf, bytes, out);
 	unsigned *ub;
 	if (hipExtMallocWithFlags((void **)&ub, bytes, hipDeviceMallocUncached) == hipSuccess) {
 		CK(hipMemset(ub, 0, bytes));

@@ -90,10 +90,9 @@ def cmd_traffic(src, out, tag):
         "calibration": {"kernel": "dist_pairs_kernel", "known_bytes": known, "fetch_size_bytes": cal["FETCH_SIZE"] * 1024.0,
                         "correction": corr, "rdreq_breakdown_bytes": rd_bytes(cal), "rdreq_correction": rd_corr,
                         "note": "same 8-lanes-x-16-B row gather as the traversal; gfx950 FETCH_SIZE reads ~1/2 of such streams",
-                        # what the chip delivers on this access pattern and nothing else: the practical ceiling of a
-                        # kernel that gathers random 384-byte rows (launch durations from the same csv rows)
+                        # launch durations from the same csv rows (the pure access pattern: tools/micro/probe_rate.hip)
                         "duration_ms": sum(cal_ns) / len(cal_ns) * 1e-6,
-                        "random_row_gather_gbs": known / (sum(cal_ns) / len(cal_ns) * 1e-9) / 1e9},
+                        "rate_gbs": known / (sum(cal_ns) / len(cal_ns) * 1e-9) / 1e9},
         "traverse": {
             "kernel": kernel_of(kname), "launches": 3, "algorithmic_bytes_per_launch": alg,
             "fetch_size_bytes_per_launch": fetch, "read_bytes_per_launch": reads,
