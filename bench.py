@@ -418,10 +418,10 @@ def cpu_baseline_leg(pl, args, sample):
 
 def traffic_record(pl, kernel):
     """HBM bytes per traversal launch from the committed PMC passes of THIS workload (profiles/), if any."""
-    name = f"pmc_traffic_{pl.n // 1_000_000}m_{pl.args.preset}.json"
+    name = f"pmc_traffic_{pl.n // 1_000_000}m_{pl.args.preset}{'_clustered' if pl.clustered else ''}.json"
     for rnd in ("r3", "r2", "r1"):
         f = os.path.join(ROOT, "profiles", rnd, name)
-        if pl.n % 1_000_000 == 0 and pl.dim == 384 and pl.nq == 1000 and not pl.clustered and os.path.exists(f):
+        if pl.n % 1_000_000 == 0 and pl.dim == 384 and pl.nq == 1000 and os.path.exists(f):
             with open(f) as fh:
                 doc = json.load(fh)
             rec = doc.get("traverse", {})
@@ -621,7 +621,9 @@ def run_hnsw(args, torch, dist, dev, rank, world):
             sustained=r2.get("sustained", {}).get("value"), recall_at_10=rec2, build_seconds=round(p2.build_s, 2),
             mean_n_dist=float(c2[:, 0].mean()), mean_n_l0lists=float(c2[:, 1].mean()),
             frac=rf2["frac"], avg_launch_ms=rf2["avg_launch_ms"], effective_gbs=rf2["effective_gbs"],
-            effective_frac=rf2["effective_frac"], algorithmic_bytes_per_launch=rf2["algorithmic_bytes_per_launch"])
+            effective_frac=rf2["effective_frac"], algorithmic_bytes_per_launch=rf2["algorithmic_bytes_per_launch"],
+            traffic=rf2.get("traffic"), traffic_source=rf2.get("traffic_source"),
+            chip_traffic_gbs_sustained=rf2.get("chip_traffic_gbs_sustained"))
         # the same per-launch definition as `frac`, on the set where the index has neighbourhoods to find
         out["roofline"]["frac_structured"] = rf2["frac"]
         out["roofline"]["structured"] = dict(value=r2["value"], unit="queries/s", recall_at_10=rec2,
