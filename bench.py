@@ -185,6 +185,8 @@ class Pipeline:
         log(f"rank {rank} [{label}]: built {self.bridge.elementCount()} nodes in {self.build_s:.1f}s")
         self.bridge.attachF32(self.base, resident=not args.host_f32)
         self.bridge.setTuning(traverse_waves=args.traverse_waves, rerank_waves=2 if args.in_flight >= 2 else 0)
+        if args.no_relabel:
+            self.bridge.setRelabel(False)
         # queries: replicated in sharded mode, per-rank otherwise
         q_seed = 54321 + (rank if (world > 1 and not sharded) else 0)
         self.q_host = make_queries(self.nb, self.nq, self.dim, q_seed, self.base, clustered)
@@ -846,6 +848,8 @@ def main():
                     help="scan workload: sweeps in flight, each on its own stream")
     ap.add_argument("--traverse-waves", type=int, default=0, choices=[0, 1],
                     help="0 = the engine's default (lean traversal + result-heap replay); 1 = the one-wave kernel with the result heap inside")
+    ap.add_argument("--no-relabel", action="store_true",
+                    help="walk the index under its own node ids (default: the traversal's copy in breadth-first label order, mvdb_set_relabel)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="wiring rehearsal of the N>1 path on a one-GPU box: every rank uses cuda:0 and the exchange "
                          "goes over gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing")

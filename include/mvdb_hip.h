@@ -260,6 +260,14 @@ int mvdb_set_tuning(mvdb_index *h, int traverse_waves, int rerank_waves);
 int mvdb_check_errors(mvdb_index *h);
 /* Device-mirror traffic since mvdb_create: out3 = {full uploads, incremental patches, nodes patched}. */
 void mvdb_upload_counters(const mvdb_index *h, long long *out3);
+/* The traversal's copy of the index under a locality order of the node labels (breadth-first over the layer-0 lists
+ * from the entry point: neighbours share visited-bitmap lines and DRAM pages where the data has neighbourhoods; node
+ * ids are labels to search_layer, hnsw.ts:423-523, so results do not change -- csrc/device_index.hpp).  On by
+ * default: every full upload of the mirror builds it (costs a second copy of rows and lists in HBM), an incremental
+ * patch drops it until the next full upload.  mvdb_set_relabel(h, 0) turns it off (the next search uploads again);
+ * mvdb_relabelled = 1 while traversals walk the relabelled copy.  No reference counterpart. */
+void mvdb_set_relabel(mvdb_index *h, int on);
+int mvdb_relabelled(const mvdb_index *h);
 /* Test hook: query index `query` of every following traversal launch takes the abort
  * path (-1 = off). */
 void mvdb_debug_inject_abort(mvdb_index *h, int query);

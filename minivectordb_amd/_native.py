@@ -79,6 +79,8 @@ SYMBOLS = [
     ("mvdb_upload_counters", None, [_vp, _vp]),
     ("mvdb_debug_inject_abort", None, [_vp, _i]),
     ("mvdb_debug_inject_build_failure", None, [_vp, _i]),
+    ("mvdb_set_relabel", None, [_vp, _i]),
+    ("mvdb_relabelled", _i, [_vp]),
     ("mvdb_lean_fallbacks", None, [_vp, _vp]),
     ("mvdb_lean_replays", None, [_vp, _vp]),
     ("mvdb_debug_set_lean_log_cap", None, [_vp, _i]),

@@ -129,6 +129,13 @@ class HipBridge:
         self._L.mvdb_upload_counters(self.handle, out)
         return dict(full_uploads=out[0], patches=out[1], nodes_patched=out[2])
 
+    def setRelabel(self, on: bool):
+        """Walk the index under a locality order of the node labels (mvdb_set_relabel; on by default)."""
+        self._L.mvdb_set_relabel(self.handle, 1 if on else 0)
+
+    def relabelled(self) -> bool:
+        return bool(self._L.mvdb_relabelled(self.handle))
+
     def leanFallbacks(self) -> dict:
         """Queries the lean traversal handed to the one-wave kernel, by reason (mvdb_lean_fallbacks)."""
         out = (C.c_longlong * 3)()

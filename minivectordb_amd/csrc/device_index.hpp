@@ -54,8 +54,22 @@ public:
 	void release();
 	long long full_uploads = 0, patches = 0, nodes_patched = 0;
 
+	// A second copy of the arrays the traversal walks -- rows, layer-0 lists, upper lists -- under another LABELLING of
+	// the nodes: breadth-first order over the layer-0 lists from the entry point, so that the neighbours a list names
+	// share visited-bitmap lines and DRAM pages wherever the data has neighbourhoods.  Node ids are labels to
+	// search_layer (its heaps compare distances only, hnsw.ts:141-315; nothing orders by id), so a traversal over the
+	// relabelled arrays makes the reference's decisions one for one, and `perm` (new label -> id) translates its output.
+	// Built by upload() (skipped quietly when the memory is not there), dropped by patch(): an edited mirror is walked
+	// under its own ids until the next full upload.  Everything that is not a traversal keeps using `view`.
+	DevIndexView view_r{};
+	const int32_t *perm = nullptr;  // device array, nullptr = no relabelled copy
+	bool relabel_enabled = true;
+
 private:
 	void *d_vec_ = nullptr, *d_adj0_ = nullptr, *d_upper_ = nullptr, *d_norm2_ = nullptr;
+	void *d_vec_r_ = nullptr, *d_adj0_r_ = nullptr, *d_upper_r_ = nullptr, *d_perm_ = nullptr;
+	void relabel(const HostGraph &g, const std::vector<int32_t> &adj, const std::vector<int2> &up);
+	void drop_relabelled();
 	// host-side bookkeeping of the mirror
 	std::vector<int32_t> code_;      // per node: (index of its layer-1 list << 2) | level, as uploaded
 	std::vector<int8_t> dev_level_;  // level as uploaded, -1 = absent on the device

@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_index.hpp"
@@ -61,8 +62,20 @@ struct DevBuf {
 }  // namespace
 
 // --------------------------------------------------------------------------- DeviceIndex
+void DeviceIndex::drop_relabelled()
+{
+	(void)hipFree(d_vec_r_);  // (hipFree waits for the device: no traversal still walks these)
+	(void)hipFree(d_adj0_r_);
+	(void)hipFree(d_upper_r_);
+	(void)hipFree(d_perm_);
+	d_vec_r_ = d_adj0_r_ = d_upper_r_ = d_perm_ = nullptr;
+	perm = nullptr;
+	view_r = DevIndexView{};
+}
+
 void DeviceIndex::release()
 {
+	drop_relabelled();
 	(void)hipFree(d_vec_);
 	(void)hipFree(d_adj0_);
 	(void)hipFree(d_upper_);
@@ -174,16 +187,16 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 	}
 
 	// layer 0, canonicalised (see device_index.hpp)
+	std::vector<int32_t> adj((size_t)N * m0);
 	{
-		std::vector<int32_t> adj((size_t)N * m0);
 		for (int i = 0; i < N; i++) canon_adj0(g, i, adj.data() + (size_t)i * m0);
 		bytes_adj0 = adj.size() * 4;
 		if (!check(hipMalloc(&d_adj0_, std::max<size_t>(bytes_adj0, 256)), "hipMalloc(adj0)")) return false;
 		if (!check(hipMemcpy(d_adj0_, adj.data(), bytes_adj0, hipMemcpyHostToDevice), "copy adj0")) return false;
 	}
 	// upper layers as (id, code) pairs
+	std::vector<int2> up((size_t)n_lists_ * m, make_int2(-1, -1));
 	{
-		std::vector<int2> up((size_t)n_lists_ * m, make_int2(-1, -1));
 		for (int i = 0; i < N; i++) {
 			const int lvl = g.level[i];
 			if (lvl < 1) continue;
@@ -199,7 +212,87 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 	view.vec = static_cast<const int8_t *>(d_vec_);
 	view.adj0 = static_cast<const int32_t *>(d_adj0_);
 	view.upper = static_cast<const int2 *>(d_upper_);
+	if (relabel_enabled && N >= 2) relabel(g, adj, up);
 	return true;
+}
+
+namespace {
+// dst row r <- src row perm[r], rows of row_bytes (a multiple of 16), one 16-byte piece per thread
+__global__ void gather_rows_kernel(uint4 *dst, const uint4 *src, const int32_t *perm, size_t pieces_per_row, size_t n_pieces)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_pieces) return;
+	const size_t r = i / pieces_per_row, c = i - r * pieces_per_row;
+	dst[i] = src[(size_t)perm[r] * pieces_per_row + c];
+}
+}  // namespace
+
+// The relabelled copy (device_index.hpp).  `adj` and `up` are the canonical lists upload() has just sent.
+void DeviceIndex::relabel(const HostGraph &g, const std::vector<int32_t> &adj, const std::vector<int2> &up)
+{
+	const int N = g.max_elements, m0 = g.cfg.m0();
+	// breadth-first order over the layer-0 lists, from the entry point; further components and, last, the absent ids
+	// follow in id order.  order[] doubles as the queue.
+	std::vector<int32_t> order((size_t)N), inv((size_t)N, -1);
+	int w = 0, r = 0, scan = 0;
+	auto found = [&](int id) {
+		inv[id] = w;
+		order[w++] = id;
+	};
+	if (g.present(g.entry_point)) found(g.entry_point);
+	for (;;) {
+		while (r < w) {
+			const int32_t *l = adj.data() + (size_t)order[r++] * m0;
+			for (int j = 0; j < m0 && l[j] >= 0; j++)
+				if (inv[l[j]] < 0) found(l[j]);
+		}
+		while (scan < N && (g.level[scan] < 0 || inv[scan] >= 0)) scan++;
+		if (scan >= N) break;
+		found(scan);
+	}
+	for (int i = 0; i < N; i++)
+		if (inv[i] < 0) found(i);
+	// lists under the new labels: the list of label a is the list of node order[a], its entries translated, in list order
+	std::vector<int32_t> adj_r((size_t)N * m0);
+	std::vector<int2> up_r(up);  // same list order (the codes index it), neighbour labels translated
+	{
+		const int nt = N >= (1 << 18) ? 8 : 1;
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; t++)
+			th.emplace_back([&, t] {
+				for (int a = (int)((int64_t)N * t / nt), a1 = (int)((int64_t)N * (t + 1) / nt); a < a1; a++) {
+					const int32_t *src = adj.data() + (size_t)order[a] * m0;
+					int32_t *dst = adj_r.data() + (size_t)a * m0;
+					for (int j = 0; j < m0; j++) dst[j] = src[j] >= 0 ? inv[src[j]] : -1;
+				}
+				for (size_t i = up_r.size() * t / nt, i1 = up_r.size() * (t + 1) / nt; i < i1; i++)
+					if (up_r[i].x >= 0) up_r[i].x = inv[up_r[i].x];
+			});
+		for (auto &x : th) x.join();
+	}
+	const bool ok = hipMalloc(&d_perm_, (size_t)N * 4) == hipSuccess &&
+	                hipMalloc(&d_vec_r_, std::max<size_t>(bytes_vec, 256)) == hipSuccess &&
+	                hipMalloc(&d_adj0_r_, std::max<size_t>(bytes_adj0, 256)) == hipSuccess &&
+	                hipMalloc(&d_upper_r_, std::max<size_t>(bytes_upper, 256)) == hipSuccess &&
+	                hipMemcpy(d_perm_, order.data(), (size_t)N * 4, hipMemcpyHostToDevice) == hipSuccess &&
+	                hipMemcpy(d_adj0_r_, adj_r.data(), bytes_adj0, hipMemcpyHostToDevice) == hipSuccess &&
+	                (up_r.empty() || hipMemcpy(d_upper_r_, up_r.data(), up_r.size() * sizeof(int2), hipMemcpyHostToDevice) == hipSuccess);
+	if (ok) {
+		const size_t ppr = (size_t)view.row_stride / 16, np = (size_t)N * ppr;
+		hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, nullptr, static_cast<uint4 *>(d_vec_r_),
+		                   static_cast<const uint4 *>(d_vec_), static_cast<const int32_t *>(d_perm_), ppr, np);
+	}
+	if (!ok || hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+		(void)hipGetLastError();  // out of memory for the copy: the traversal walks the arrays under their own ids
+		drop_relabelled();
+		return;
+	}
+	view_r = view;
+	view_r.vec = static_cast<const int8_t *>(d_vec_r_);
+	view_r.adj0 = static_cast<const int32_t *>(d_adj0_r_);
+	view_r.upper = static_cast<const int2 *>(d_upper_r_);
+	if (g.present(g.entry_point)) view_r.entry = inv[g.entry_point];
+	perm = static_cast<const int32_t *>(d_perm_);
 }
 
 namespace {
@@ -224,6 +317,7 @@ int DeviceIndex::patch(const HostGraph &g, std::string &err)
 		return 1;
 	}
 	if (nd > (size_t)N / 4) return 0;  // a full upload is cheaper
+	drop_relabelled();  // the edited mirror is walked under its own ids until the next full upload
 	const int stride = view.row_stride;
 	// new nodes first: their codes are named by the lists of the other dirty nodes
 	int64_t new_lists = 0;  // upper lists the whole batch appends into the slack
@@ -1042,7 +1136,8 @@ void traverse_params(mvdb_index *h, int k, TraverseArgs &a, bool set_only)
 	int cand_cap = ef * 2 + 32;  // hnsw.ts:443-445
 	if (cand_cap > kMaxEf) cand_cap = kMaxEf;
 	if (cand_cap < ef) cand_cap = ef;
-	a.ix = h->dev.view;
+	a.ix = h->dev.perm ? h->dev.view_r : h->dev.view;  // the relabelled copy when there is one (device_index.hpp)
+	a.perm = h->dev.perm;
 	a.k = k;
 	a.ef = ef;
 	a.cand_cap = cand_cap;
@@ -1750,6 +1845,14 @@ void mvdb_upload_counters(const mvdb_index *h, long long *out3)
 	out3[1] = h->dev.patches;
 	out3[2] = h->dev.nodes_patched;
 }
+
+void mvdb_set_relabel(mvdb_index *h, int on)
+{
+	if (h->dev.relabel_enabled == (on != 0)) return;
+	h->dev.relabel_enabled = on != 0;
+	h->dev.built_version = ~0ull;  // the next search uploads again, with or without the relabelled copy
+}
+int mvdb_relabelled(const mvdb_index *h) { return h->dev.perm != nullptr; }
 
 void mvdb_debug_inject_abort(mvdb_index *h, int query) { h->inject_abort_q = query; }
 void mvdb_debug_inject_build_failure(mvdb_index *h, int pass) { h->inject_build_fail_pass = pass; }

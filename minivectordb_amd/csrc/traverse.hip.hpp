@@ -375,6 +375,7 @@ struct TraverseArgs {
 	int *flag;            // nq: kLeanDone, or why the query is left to traverse_kernel
 	int *lean_stats;      // device-mapped host counters of the handle, indexed by flag value, or null
 	int *fb_list, *fb_n;  // queries traverse_lean_kernel hands to traverse_flagged_kernel (flags 1..3), and their number
+	const int32_t *perm;  // ix is the relabelled copy of the index (device_index.hpp): label -> node id for every id written out; nullptr = ids are labels
 };
 
 // An aborted query (the test hook) is reported three ways: out_count = -1,
@@ -626,7 +627,7 @@ __device__ __forceinline__ void traverse_query(const TraverseArgs &a, const int 
 	if (out_count > MVDB_MAX_EF) out_count = MVDB_MAX_EF;
 	for (int i = lane; i < out_count; i += 64) {  // :1019-1024
 		const uint2 e = cand_h[i];
-		a.out_ids[(size_t)qi * (size_t)a.k + i] = (int)e.y;
+		a.out_ids[(size_t)qi * (size_t)a.k + i] = a.perm ? a.perm[e.y] : (int)e.y;
 		a.out_dist[(size_t)qi * (size_t)a.k + i] = __uint_as_float(e.x);
 	}
 	for (int i = out_count + lane; i < a.k; i += 64) {  // deterministic tail of a ragged row

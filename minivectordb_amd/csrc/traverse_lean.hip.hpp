@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 						const unsigned long long km = __ballot(keep);
 						if (keep) {
 							const int o = pos + __builtin_popcountll(km & lean_lt_mask(lane));
-							oid[o] = (int)e[u].y;
+							oid[o] = a.perm ? a.perm[e[u].y] : (int)e[u].y;
 							od[o] = (float)e[u].x;  // keys as the reference holds them: the f32 value of the integer distance (math.ts:126)
 						}
 						pos += __builtin_popcountll(km);
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 	if (unsorted) {
 		for (int i = lane; i < out_count; i += 64) {
 			const uint2 e = res_h[1 + i];
-			oid[i] = (int)e.y;
+			oid[i] = a.perm ? a.perm[e.y] : (int)e.y;
 			od[i] = __uint_as_float(e.x);
 		}
 	} else if (sorted_lds) {
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 		rpipe.drain();
 		for (int i = lane; i < out_count; i += 64) {  // :1019-1024
 			const uint2 e = out_s[i];
-			oid[i] = (int)e.y;
+			oid[i] = a.perm ? a.perm[e.y] : (int)e.y;
 			od[i] = __uint_as_float(e.x);
 		}
 	}

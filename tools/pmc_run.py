@@ -37,6 +37,8 @@ ids = np.random.default_rng(7).integers(0, n, (nq, per_q)).astype(np.int32)
 b.distMany(qi8, ids)                       # calibration: nq*per_q rows of `dim` bytes each
 tk, ef, ann_k = derive_search_params(10, p)
 b.setEfSearch(ef)
+if os.environ.get("MVDB_NO_RELABEL"):
+    b.setRelabel(False)
 for _ in range(3):
     out = b.searchManyArrays(qi8, ann_k, with_counters=True)
 ctr = out[3].astype(np.int64)
