@@ -186,7 +186,7 @@ class Pipeline:
         self.bridge.attachF32(self.base, resident=not args.host_f32)
         self.bridge.setTuning(traverse_waves=args.traverse_waves, rerank_waves=2 if args.in_flight >= 2 else 0)
         if args.no_relabel:
-            self.bridge.setRelabel(False)
+            self.bridge.setRelabel(0)
         # queries: replicated in sharded mode, per-rank otherwise
         q_seed = 54321 + (rank if (world > 1 and not sharded) else 0)
         self.q_host = make_queries(self.nb, self.nq, self.dim, q_seed, self.base, clustered)
@@ -603,7 +603,8 @@ def run_hnsw(args, torch, dist, dev, rank, world):
                    roofline=roofline, cpu_baseline=cpu_baseline,
                    counters=dict(mean_n_dist=float(ctr_all[:, 0].mean()), mean_n_l0lists=float(ctr_all[:, 1].mean()),
                                  mean_n_upperlists=float(ctr_all[:, 2].mean())),
-                   lean_fallbacks=bridge.leanFallbacks(), lean_replays=bridge.leanReplays())
+                   lean_fallbacks=bridge.leanFallbacks(), lean_replays=bridge.leanReplays(),
+                   relabelled=bridge.relabelled())
         out.update(extras)
     pl.close()
     del pl, s, bridge
@@ -624,7 +625,7 @@ def run_hnsw(args, torch, dist, dev, rank, world):
             mean_n_dist=float(c2[:, 0].mean()), mean_n_l0lists=float(c2[:, 1].mean()),
             frac=rf2["frac"], avg_launch_ms=rf2["avg_launch_ms"], effective_gbs=rf2["effective_gbs"],
             effective_frac=rf2["effective_frac"], algorithmic_bytes_per_launch=rf2["algorithmic_bytes_per_launch"],
-            traffic=rf2.get("traffic"), traffic_source=rf2.get("traffic_source"),
+            traffic=rf2.get("traffic"), traffic_source=rf2.get("traffic_source"), relabelled=p2.bridge.relabelled(),
             chip_traffic_gbs_sustained=rf2.get("chip_traffic_gbs_sustained"))
         # the same per-launch definition as `frac`, on the set where the index has neighbourhoods to find
         out["roofline"]["frac_structured"] = rf2["frac"]

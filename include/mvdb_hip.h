@@ -262,11 +262,13 @@ int mvdb_check_errors(mvdb_index *h);
 void mvdb_upload_counters(const mvdb_index *h, long long *out3);
 /* The traversal's copy of the index under a locality order of the node labels (breadth-first over the layer-0 lists
  * from the entry point: neighbours share visited-bitmap lines and DRAM pages where the data has neighbourhoods; node
- * ids are labels to search_layer, hnsw.ts:423-523, so results do not change -- csrc/device_index.hpp).  On by
- * default: every full upload of the mirror builds it (costs a second copy of rows and lists in HBM), an incremental
- * patch drops it until the next full upload.  mvdb_set_relabel(h, 0) turns it off (the next search uploads again);
+ * ids are labels to search_layer, hnsw.ts:423-523, so results do not change -- csrc/device_index.hpp).
+ * mode 1 (default): every full upload of the mirror builds the order and keeps the copy if a list's neighbours then
+ * share bitmap lines (at least two per 1024-label line on average over sampled lists; i.i.d. rows do not, and run on
+ * their own ids); 2: keep it regardless (tests); 0: never.  The copy costs a second set of rows and lists in HBM; an
+ * incremental patch drops it until the next full upload; a change of mode makes the next search upload again.
  * mvdb_relabelled = 1 while traversals walk the relabelled copy.  No reference counterpart. */
-void mvdb_set_relabel(mvdb_index *h, int on);
+void mvdb_set_relabel(mvdb_index *h, int mode);
 int mvdb_relabelled(const mvdb_index *h);
 /* Test hook: query index `query` of every following traversal launch takes the abort
  * path (-1 = off). */

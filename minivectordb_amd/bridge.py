@@ -129,9 +129,10 @@ class HipBridge:
         self._L.mvdb_upload_counters(self.handle, out)
         return dict(full_uploads=out[0], patches=out[1], nodes_patched=out[2])
 
-    def setRelabel(self, on: bool):
-        """Walk the index under a locality order of the node labels (mvdb_set_relabel; on by default)."""
-        self._L.mvdb_set_relabel(self.handle, 1 if on else 0)
+    def setRelabel(self, mode):
+        """The traversal's copy of the index in breadth-first label order (mvdb_set_relabel): True / 1 = kept when it
+        makes lists local (the default), 2 = always, False / 0 = never."""
+        self._L.mvdb_set_relabel(self.handle, int(mode))
 
     def relabelled(self) -> bool:
         return bool(self._L.mvdb_relabelled(self.handle))

@@ -59,11 +59,15 @@ public:
 	// share visited-bitmap lines and DRAM pages wherever the data has neighbourhoods.  Node ids are labels to
 	// search_layer (its heaps compare distances only, hnsw.ts:141-315; nothing orders by id), so a traversal over the
 	// relabelled arrays makes the reference's decisions one for one, and `perm` (new label -> id) translates its output.
-	// Built by upload() (skipped quietly when the memory is not there), dropped by patch(): an edited mirror is walked
-	// under its own ids until the next full upload.  Everything that is not a traversal keeps using `view`.
+	// Built by upload() -- and kept only if it pays: when a list's neighbours do not end up sharing bitmap lines
+	// (i.i.d. rows have no neighbourhoods to find) the copy is dropped again, and with it the translation of the output
+	// (relabel_mode 1; 2 = keep it regardless, 0 = never build it).  Skipped quietly when the memory is not there,
+	// dropped by patch(): an edited mirror is walked under its own ids until the next full upload.  Everything that is
+	// not a traversal keeps using `view`.
 	DevIndexView view_r{};
 	const int32_t *perm = nullptr;  // device array, nullptr = no relabelled copy
-	bool relabel_enabled = true;
+	int relabel_mode = 1;
+	double relabel_lines_per_list = 0, relabel_entries_per_list = 0;  // sampled: bitmap lines / entries per layer-0 list under the new labels
 
 private:
 	void *d_vec_ = nullptr, *d_adj0_ = nullptr, *d_upper_ = nullptr, *d_norm2_ = nullptr;

@@ -212,7 +212,7 @@ bool DeviceIndex::upload(const HostGraph &g, std::string &err)
 	view.vec = static_cast<const int8_t *>(d_vec_);
 	view.adj0 = static_cast<const int32_t *>(d_adj0_);
 	view.upper = static_cast<const int2 *>(d_upper_);
-	if (relabel_enabled && N >= 2) relabel(g, adj, up);
+	if (relabel_mode != 0 && N >= 2) relabel(g, adj, up);
 	return true;
 }
 
@@ -252,6 +252,24 @@ void DeviceIndex::relabel(const HostGraph &g, const std::vector<int32_t> &adj, c
 	}
 	for (int i = 0; i < N; i++)
 		if (inv[i] < 0) found(i);
+	// does it pay?  How many 1024-label lines of the visited bitmap do the entries of a list touch under the new labels
+	// (a uniform sample of lists; the lists expanded first would flatter the order: their neighbours were numbered by them)
+	{
+		std::vector<int32_t> tv((size_t)m0);
+		double lines = 0, entries = 0;
+		const int step = std::max(1, N / 4096);
+		for (int i = 0; i < N; i += step) {
+			const int32_t *l = adj.data() + (size_t)i * m0;
+			int c = 0;
+			for (int j = 0; j < m0 && l[j] >= 0; j++) tv[c++] = inv[l[j]] >> 10;
+			std::sort(tv.begin(), tv.begin() + c);
+			lines += (double)(std::unique(tv.begin(), tv.begin() + c) - tv.begin());
+			entries += c;
+		}
+		relabel_lines_per_list = lines;
+		relabel_entries_per_list = entries;
+		if (relabel_mode == 1 && 2 * lines > entries) return;  // fewer than two neighbours per line: no neighbourhoods to exploit (i.i.d. rows)
+	}
 	// lists under the new labels: the list of label a is the list of node order[a], its entries translated, in list order
 	std::vector<int32_t> adj_r((size_t)N * m0);
 	std::vector<int2> up_r(up);  // same list order (the codes index it), neighbour labels translated
@@ -688,10 +706,14 @@ int launch_replay(mvdb_index *h, const TraverseArgs &a, hipStream_t s)
 	const bool may_sort = !(a.set_only && a.ef <= a.k && a.ef <= a.results_cap);
 	const size_t lds = replay_lds_bytes(a.ef, may_sort);
 	static int mark[16] = {0};
-	if (!set_max_lds(h, reinterpret_cast<const void *>(&replay_kernel), mark, lds)) return 0;
+	static int pmark[16] = {0};
+	if (!(a.perm ? set_max_lds(h, reinterpret_cast<const void *>(&replay_kernel<true>), pmark, lds)
+	             : set_max_lds(h, reinterpret_cast<const void *>(&replay_kernel<false>), mark, lds)))
+		return 0;
 	TraverseArgs r = a;
 	r.lean_stats = static_cast<int *>(h->replay_stats.p);  // replay_kernel counts in device memory
-	hipLaunchKernelGGL(replay_kernel, dim3(a.nq), dim3(64), lds, s, r, may_sort ? 1 : 0);
+	if (a.perm) hipLaunchKernelGGL(replay_kernel<true>, dim3(a.nq), dim3(64), lds, s, r, may_sort ? 1 : 0);
+	else hipLaunchKernelGGL(replay_kernel<false>, dim3(a.nq), dim3(64), lds, s, r, may_sort ? 1 : 0);
 	HIP_OK(h, hipGetLastError());
 	return 1;
 }
@@ -1846,10 +1868,11 @@ void mvdb_upload_counters(const mvdb_index *h, long long *out3)
 	out3[2] = h->dev.nodes_patched;
 }
 
-void mvdb_set_relabel(mvdb_index *h, int on)
+void mvdb_set_relabel(mvdb_index *h, int mode)
 {
-	if (h->dev.relabel_enabled == (on != 0)) return;
-	h->dev.relabel_enabled = on != 0;
+	mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+	if (h->dev.relabel_mode == mode) return;
+	h->dev.relabel_mode = mode;
 	h->dev.built_version = ~0ull;  // the next search uploads again, with or without the relabelled copy
 }
 int mvdb_relabelled(const mvdb_index *h) { return h->dev.perm != nullptr; }

@@ -917,6 +917,9 @@ __host__ __device__ inline size_t replay_lds_bytes(int ef, bool sorted)
 	return (heap < 1024 ? 1024 : heap) + (sorted ? (size_t)8 * (size_t)((ef + 1) & ~1) : 0);
 }
 
+// PERM: the labels of the log are translated into node ids on the way out (TraverseArgs::perm; a template flag, not a
+// test per entry: with the test inside, hipcc gives up the four-deep load batches of the loops below)
+template <bool PERM>
 __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_lds)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1012,13 +1015,23 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 						const int i = c0 + u * 64 + lane;
 						e[u] = log[i < n_adm ? i : 0];
 					}
+					bool keep[4];
+					int idv[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++) keep[u] = c0 + u * 64 + lane < n_adm && e[u].x <= W;
+#pragma unroll
+					for (int u = 0; u < 4; u++) idv[u] = (int)e[u].y;
+					if (PERM) {  // label -> node id, for the entries that stay only, the four gathers in flight together
+#pragma unroll
+						for (int u = 0; u < 4; u++)
+							if (keep[u]) idv[u] = a.perm[e[u].y];
+					}
 #pragma unroll
 					for (int u = 0; u < 4; u++) {
-						const bool keep = c0 + u * 64 + lane < n_adm && e[u].x <= W;
-						const unsigned long long km = __ballot(keep);
-						if (keep) {
+						const unsigned long long km = __ballot(keep[u]);
+						if (keep[u]) {
 							const int o = pos + __builtin_popcountll(km & lean_lt_mask(lane));
-							oid[o] = a.perm ? a.perm[e[u].y] : (int)e[u].y;
+							oid[o] = idv[u];
 							od[o] = (float)e[u].x;  // keys as the reference holds them: the f32 value of the integer distance (math.ts:126)
 						}
 						pos += __builtin_popcountll(km);
@@ -1062,7 +1075,7 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 	if (unsorted) {
 		for (int i = lane; i < out_count; i += 64) {
 			const uint2 e = res_h[1 + i];
-			oid[i] = a.perm ? a.perm[e.y] : (int)e.y;
+			oid[i] = PERM ? a.perm[e.y] : (int)e.y;
 			od[i] = __uint_as_float(e.x);
 		}
 	} else if (sorted_lds) {
@@ -1082,7 +1095,7 @@ __global__ __launch_bounds__(64) void replay_kernel(TraverseArgs a, int sorted_l
 		rpipe.drain();
 		for (int i = lane; i < out_count; i += 64) {  // :1019-1024
 			const uint2 e = out_s[i];
-			oid[i] = a.perm ? a.perm[e.y] : (int)e.y;
+			oid[i] = PERM ? a.perm[e.y] : (int)e.y;
 			od[i] = __uint_as_float(e.x);
 		}
 	}

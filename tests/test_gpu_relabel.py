@@ -56,17 +56,19 @@ def test_same_answers_with_and_without_the_relabelled_copy(gpu, style):
     qn = O.normalize_rows_f32(q)
     q8 = O.quantize_rows_i8(qn)
     fused = {}
-    for on in (True, False, True):
-        b.setRelabel(on)
+    for mode in (2, 0, 1):                        # always / never / kept only where lists become local (the default)
+        b.setRelabel(mode)
         for k, ef in [(10, 40), (200, 200), (64, 700)]:
-            _check(b, ix, q8, k, ef, f"{style} relabel={on}")
-        assert b.relabelled() == on
-        fused[on] = b.queryMany(q, 10, 300, 300)
-    for x, y in zip(fused[True], fused[False]):
-        assert np.array_equal(x, y)
+            _check(b, ix, q8, k, ef, f"{style} relabel={mode}")
+        if mode != 1 or style == "clustered":     # (mode 1 keeps the copy where lists become local; 12 bitmap lines in all make any list "local")
+            assert b.relabelled() == (mode != 0)
+        fused[mode] = b.queryMany(q, 10, 300, 300)
+    for other in (0, 1):
+        for x, y in zip(fused[2], fused[other]):
+            assert np.array_equal(x, y)
     fi, fd, fc, _ = (ix.set_ef_search(300), ix.search_many(q8, 300, threads=8))[1]
     e_ids, e_l2, e_n = O.rerank_many(qn, base, fi, fc, 300, 10, threads=8)
-    assert np.array_equal(fused[True][0], e_ids) and np.array_equal(fused[True][1].view(np.uint64), e_l2.view(np.uint64))
+    assert np.array_equal(fused[2][0], e_ids) and np.array_equal(fused[2][1].view(np.uint64), e_l2.view(np.uint64))
     b.close()
     ix.close()
 
@@ -85,6 +87,7 @@ def test_holes_components_and_an_edit(gpu):
     ix.insert_many(ids, b8)
     b = _bridge(ix, dim, m, efc)
     q8 = O.quantize_rows_i8(O.normalize_rows_f32(base[rng.integers(0, n, 48)] + np.float32(0.05) * rng.standard_normal((48, dim), dtype=np.float32)))
+    b.setRelabel(2)
     _check(b, ix, q8, 50, 120, "holes")
     assert b.relabelled()
     extra = O.quantize_rows_i8(_clustered(rng, 40, dim))
@@ -98,8 +101,8 @@ def test_holes_components_and_an_edit(gpu):
     up = b.uploadCounters()
     if up["patches"] >= 1:                                               # the mirror was edited in place
         assert not b.relabelled()
-    b.setRelabel(False)
-    b.setRelabel(True)                                                   # forces the next search to upload again
+    b.setRelabel(0)
+    b.setRelabel(2)                                                      # forces the next search to upload again
     _check(b, ix, q8, 50, 120, "after the re-upload")
     assert b.relabelled()
     b.close()

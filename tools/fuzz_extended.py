@@ -8,6 +8,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_fuzz import test_random_graphs_sorted_and_fused as one
 
 if __name__ == "__main__":
+    if os.environ.get("MVDB_RELABEL_ALWAYS"):   # every graph of the sweep walked under breadth-first labels (mvdb_set_relabel mode 2)
+        from minivectordb_amd import HipBridge
+        _init = HipBridge.init
+        def init(self, *a, **k):
+            r = _init(self, *a, **k)
+            self.setRelabel(2)
+            return r
+        HipBridge.init = init
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 48
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     budget = float(sys.argv[3]) if len(sys.argv) > 3 else 600.0

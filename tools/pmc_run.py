@@ -38,7 +38,7 @@ b.distMany(qi8, ids)                       # calibration: nq*per_q rows of `dim`
 tk, ef, ann_k = derive_search_params(10, p)
 b.setEfSearch(ef)
 if os.environ.get("MVDB_NO_RELABEL"):
-    b.setRelabel(False)
+    b.setRelabel(0)
 for _ in range(3):
     out = b.searchManyArrays(qi8, ann_k, with_counters=True)
 ctr = out[3].astype(np.int64)

@@ -23,7 +23,7 @@ if __name__ == "__main__":
     b.buildGpu(q8)
     b.setTuning(traverse_waves=0)
     if os.environ.get("MVDB_NO_RELABEL"):
-        b.setRelabel(False)
+        b.setRelabel(0)
     q = bench.make_queries(1, nq, dim, 54321, qn, clustered)[0]
     _, qi8 = b.prepareQueries(q)
     tk, ef, ann_k = derive_search_params(10, p)

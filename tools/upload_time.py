@@ -16,7 +16,7 @@ if __name__ == "__main__":
     b.buildGpu(q8)
     b.setEfSearch(64)
     q = q8[:8]
-    for on in (True, False, True, False):
+    for on in (2, 0, 1, 0):   # always / never / adaptive / never
         b.setRelabel(on)
         t0 = time.perf_counter(); b.searchManyArrays(q, 10); t1 = time.perf_counter()
         b.searchManyArrays(q, 10); t2 = time.perf_counter()
